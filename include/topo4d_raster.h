@@ -1,0 +1,143 @@
+/*
+ * topo4d_raster.h — C ABI of the MI355X-native differentiable Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of Topo4D: the rasterizer behind
+ *     im, radius, depth, alpha = Renderer(raster_settings=cam)(**rendervar)
+ * (/root/reference train.py:307, :388, :463, :484; imports train.py:19, helpers.py:18-19).
+ * Upstream binds that path through a pybind11 module `diff_gaussian_rasterization._C` with the entry points
+ * `rasterize_gaussians`, `rasterize_gaussians_backward` and `mark_visible` (not vendored in the reference —
+ * README.md:22-24).  The functions below are what a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md; the shipped Python host side is topo4d_amd/rasterizer.py):
+ *
+ *   t4d_rasterize_forward   <->  _C.rasterize_gaussians            (called from train.py:307/388/463/484)
+ *   t4d_rasterize_backward  <->  _C.rasterize_gaussians_backward   (reached from loss.backward(), train.py:667/738)
+ *   t4d_mark_visible        <->  _C.mark_visible                   (GaussianRasterizer.markVisible; unused by Topo4D)
+ *   t4d_state_bytes / t4d_backward_scratch_bytes  <->  upstream's resize-callback buffers (geom/binning/img)
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (fp32 unless noted), sizes, and a hipStream_t passed as void*.
+ *     No torch types.  The library never allocates or frees device memory and never synchronises the
+ *     stream unless T4D_FLAG_CHECKED / T4D_FLAG_DEBUG_SYNC asks for it.
+ *   - one call renders n_views views of the SAME P Gaussians (the 24 cameras of a Topo4D frame, or one rank's
+ *     shard of them); n_views = 1 is the reference's call shape.  All views share H and W.
+ *   - per-view camera record = T4D_VIEW_FLOATS floats on the device, built from the fields of
+ *     GaussianRasterizationSettings (helpers.py:73-86):
+ *        [0..15]  viewmatrix  — the 16 floats of the [1,4,4] tensor helpers.py:67 builds (transposed w2c ⇒
+ *                 element (row r, col c) of the mathematical matrix sits at [c*4+r])
+ *        [16..31] projmatrix  — same layout (helpers.py:71-72)
+ *        [32..34] campos      [35..37] bg      [38] tanfovx      [39] tanfovy
+ *   - outputs are planar, one image after another: color [V,3,H,W], depth [V,1,H,W], alpha [V,1,H,W],
+ *     radii int32 [V,P] — for V = 1 exactly the four tensors train.py:307 unpacks.
+ *   - gradients are per view: dL_dX has a leading V dimension; the caller sums over views if it wants the
+ *     gradient of a multi-view loss (or passes T4D_FLAG_... none: summation is not done here).
+ *   - every function returns T4D_OK (0) or an error code; nothing throws or exits across the ABI.
+ */
+#ifndef TOPO4D_RASTER_H
+#define TOPO4D_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T4D_ABI_VERSION 1
+#define T4D_VIEW_FLOATS 40
+#define T4D_GRAD_PAIR_FLOATS 12   /* per (Gaussian,tile) partial-gradient record in the backward scratch */
+
+enum {
+    T4D_OK = 0,
+    T4D_ERR_ARG = 1,            /* bad argument combination (mirrors the upstream Python-level checks) */
+    T4D_ERR_HIP = 2,            /* a HIP runtime call failed; see t4d_last_error() */
+    T4D_ERR_PAIR_OVERFLOW = 3,  /* pair_capacity too small (CHECKED mode): status->max_pairs_per_view says how much */
+    T4D_ERR_STATE_SIZE = 4      /* state/scratch buffer smaller than t4d_*_bytes() */
+};
+
+enum {
+    T4D_FLAG_CHECKED = 1u,     /* forward: sync once after binning sizes are known and fail with PAIR_OVERFLOW
+                                  instead of rendering truncated tile lists (what upstream's num_rendered D2H does) */
+    T4D_FLAG_DEBUG_SYNC = 2u,  /* `debug=True` of the settings tuple: synchronise + check after every kernel */
+    T4D_FLAG_PREFILTERED = 4u  /* accepted for API parity (helpers.py:84 passes False); no effect */
+};
+
+typedef struct T4DProblem {
+    int32_t abi_version;     /* = T4D_ABI_VERSION */
+    int32_t n_views;         /* V */
+    int32_t P;               /* Gaussians */
+    int32_t H, W;            /* image_height, image_width */
+    int32_t sh_degree;       /* active SH degree (settings.sh_degree); used only when shs != NULL */
+    int32_t sh_coeffs;       /* M: coefficients stored per Gaussian in shs [P,M,3] */
+    float   scale_modifier;
+    int64_t pair_capacity;   /* capacity, PER VIEW, of the (Gaussian,tile) pair arena */
+    uint32_t flags;
+    uint32_t reserved;
+} T4DProblem;
+
+typedef struct T4DStatus {
+    int64_t max_pairs_per_view;  /* largest per-view number of (Gaussian,tile) pairs this call needed */
+    int64_t total_pairs;         /* sum over views (upstream's num_rendered, summed) */
+    int32_t overflow;            /* 1 if any view exceeded pair_capacity (its tile lists were truncated) */
+    int32_t reserved;
+} T4DStatus;
+
+typedef struct T4DForwardIO {
+    const float *views;           /* [V][T4D_VIEW_FLOATS] */
+    const float *means3D;         /* [P,3] */
+    const float *opacities;       /* [P] (the [P,1] tensor of helpers.py:96) */
+    const float *scales;          /* [P,3] or NULL when cov3D_precomp */
+    const float *rotations;       /* [P,4] (r,x,y,z), caller-normalised (helpers.py:95), or NULL */
+    const float *cov3D_precomp;   /* [P,6] or NULL */
+    const float *colors_precomp;  /* [P,3] or NULL when shs */
+    const float *shs;             /* [P,M,3] or NULL */
+    float   *out_color;           /* [V,3,H,W] */
+    float   *out_depth;           /* [V,1,H,W] */
+    float   *out_alpha;           /* [V,1,H,W] */
+    int32_t *out_radii;           /* [V,P] */
+    void    *state;               /* opaque, t4d_state_bytes(); must stay alive and unmodified until backward */
+    size_t   state_bytes;
+} T4DForwardIO;
+
+typedef struct T4DBackwardIO {
+    const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
+    const int32_t *radii;         /* the [V,P] forward output */
+    const void  *state;           /* the forward's state buffer */
+    size_t       state_bytes;
+    const float *dL_dcolor;       /* [V,3,H,W] */
+    const float *dL_ddepth;       /* [V,1,H,W] or NULL (= zeros; Topo4D discards depth, train.py:307) */
+    const float *dL_dalpha;       /* [V,1,H,W] or NULL */
+    float *dL_dmeans3D;           /* [V,P,3] */
+    float *dL_dmeans2D;           /* [V,P,3] (z = 0): the screen-space gradient kept alive by train.py:304 */
+    float *dL_dcolors;            /* [V,P,3]   or NULL (required when colors_precomp) */
+    float *dL_dshs;               /* [V,P,M,3] or NULL (required when shs) */
+    float *dL_dopacities;         /* [V,P] */
+    float *dL_dscales;            /* [V,P,3]   or NULL (required unless cov3D_precomp) */
+    float *dL_drotations;         /* [V,P,4]   or NULL (required unless cov3D_precomp) */
+    float *dL_dcov3D;             /* [V,P,6]   or NULL (required when cov3D_precomp) */
+    void  *scratch;               /* t4d_backward_scratch_bytes() */
+    size_t scratch_bytes;
+} T4DBackwardIO;
+
+uint32_t    t4d_abi_version(void);
+const char *t4d_last_error(void);
+
+size_t t4d_state_bytes(const T4DProblem *prob);
+size_t t4d_backward_scratch_bytes(const T4DProblem *prob);
+
+/* Forward: preprocess -> per-tile binning -> per-tile depth sort -> alpha blend.  `status` may be NULL; it is
+ * filled only in CHECKED / DEBUG_SYNC mode (otherwise use t4d_fetch_status after the stream has drained). */
+int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO *io, T4DStatus *status, void *hip_stream);
+
+/* Backward: per-tile back-to-front replay (atomic-free, deterministic) -> per-Gaussian gather + chain rule. */
+int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardIO *io, void *hip_stream);
+
+/* Copies the status block of a forward's state buffer to the host (synchronises the stream). */
+int t4d_fetch_status(const T4DProblem *prob, const void *state, T4DStatus *out, void *hip_stream);
+
+/* present[i] = 1 iff Gaussian i passes the near-plane test of view record `view` (upstream markVisible). */
+int t4d_mark_visible(int32_t P, const float *means3D, const float *view, uint8_t *present, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPO4D_RASTER_H */

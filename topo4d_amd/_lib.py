@@ -1,0 +1,99 @@
+"""
+ctypes binding of the C-ABI shared library (include/topo4d_raster.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `python -m topo4d_amd.build` with
+`hipcc --offload-arch=gfx950`.  There is NO fallback: if the shared object is missing or does not load, every
+entry point of the product raises — a rasterizer that silently ran on the CPU would void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libtopo4d_raster.so")
+
+T4D_ABI_VERSION = 1
+T4D_VIEW_FLOATS = 40
+T4D_GRAD_PAIR_FLOATS = 12
+
+T4D_OK, T4D_ERR_ARG, T4D_ERR_HIP, T4D_ERR_PAIR_OVERFLOW, T4D_ERR_STATE_SIZE = 0, 1, 2, 3, 4
+T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_PREFILTERED = 1, 2, 4
+
+# every symbol include/topo4d_raster.h declares (tests/test_abi.py checks header <-> this list <-> the .so)
+EXPORTS = (
+    "t4d_abi_version", "t4d_last_error", "t4d_state_bytes", "t4d_backward_scratch_bytes",
+    "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
+)
+
+
+class T4DProblem(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("n_views", C.c_int32), ("P", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+                ("scale_modifier", C.c_float), ("pair_capacity", C.c_int64), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class T4DStatus(C.Structure):
+    _fields_ = [("max_pairs_per_view", C.c_int64), ("total_pairs", C.c_int64), ("overflow", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class T4DForwardIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "views", "means3D", "opacities", "scales", "rotations", "cov3D_precomp", "colors_precomp", "shs",
+        "out_color", "out_depth", "out_alpha", "out_radii", "state")] + [("state_bytes", C.c_size_t)]
+
+
+class T4DBackwardIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "views", "means3D", "opacities", "scales", "rotations", "cov3D_precomp", "colors_precomp", "shs",
+        "radii", "state")] + [("state_bytes", C.c_size_t)] + [(n, C.c_void_p) for n in (
+            "dL_dcolor", "dL_ddepth", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dshs",
+            "dL_dopacities", "dL_dscales", "dL_drotations", "dL_dcov3D", "scratch")] + [
+                ("scratch_bytes", C.c_size_t)]
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libtopo4d_raster.so or raise ExtensionMissing.  Never falls back to anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m topo4d_amd.build` "
+            "(hipcc --offload-arch=gfx950). topo4d_amd has no CPU fallback by design.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ExtensionMissing(f"could not load {LIB_PATH}: {e}") from e
+    lib.t4d_abi_version.restype = C.c_uint32
+    lib.t4d_last_error.restype = C.c_char_p
+    lib.t4d_state_bytes.restype = C.c_size_t
+    lib.t4d_state_bytes.argtypes = [C.POINTER(T4DProblem)]
+    lib.t4d_backward_scratch_bytes.restype = C.c_size_t
+    lib.t4d_backward_scratch_bytes.argtypes = [C.POINTER(T4DProblem)]
+    lib.t4d_rasterize_forward.restype = C.c_int
+    lib.t4d_rasterize_forward.argtypes = [C.POINTER(T4DProblem), C.POINTER(T4DForwardIO), C.POINTER(T4DStatus),
+                                          C.c_void_p]
+    lib.t4d_rasterize_backward.restype = C.c_int
+    lib.t4d_rasterize_backward.argtypes = [C.POINTER(T4DProblem), C.POINTER(T4DBackwardIO), C.c_void_p]
+    lib.t4d_fetch_status.restype = C.c_int
+    lib.t4d_fetch_status.argtypes = [C.POINTER(T4DProblem), C.c_void_p, C.POINTER(T4DStatus), C.c_void_p]
+    lib.t4d_mark_visible.restype = C.c_int
+    lib.t4d_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if lib.t4d_abi_version() != T4D_ABI_VERSION:
+        raise ExtensionMissing(f"ABI mismatch: library {lib.t4d_abi_version()} vs python {T4D_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().t4d_last_error().decode(errors="replace")
