@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""
+bench.py — rasterizer forward+backward views/sec on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: forward + backward of the 24 views of one synthetic frame
+(BASELINE config 2: 24 x 512x512, P = 30,000 vertex-bound Gaussians, precomputed RGB) through the C ABI, with
+all inputs already resident in HBM and seeded dL/dcolor supplied.  One "view" = one
+(Settings, params) -> colour/depth/alpha -> per-view dL/dparams round trip.
+
+Multi-GPU (BASELINE config 3): the 64-frame sequence is sharded by frame — rank r renders frames r, r+N, ...;
+per-GPU work per step is fixed (24 views) => "scaling": "weak".  The only collective is an RCCL all_gather of the
+per-view scalar losses (24 floats per rank per step).  K*N = 64 steps is the strong-scaling run of config 3.
+
+The JSON line carries `roofline` (dominant kernel, HIP-event duration, algorithmic bytes per launch) and
+`cpu_baseline` (oracle/raster_oracle.c, OpenMP, bounded sample) — see DESIGN.md §Measurement.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
+ACHIEVABLE_HBM_GBS = 6290.0
+
+
+def algorithmic_bytes(P, R, HW, S=0):
+    """SURVEY.md §8d, per view.  Returns (per-kernel dict, whole-pipeline bytes)."""
+    per_kernel = {
+        "k_preprocess": P * (56 + S) + P * 60,            # param read + geometry-state write
+        "k_scan_tiles": 0,
+        "k_scatter": R * 12,                              # key/value write
+        "k_sort_tiles": R * 24,                           # one sort pass, read + write (lower bound)
+        "k_render_fwd": R * 40 + HW * 28,                 # per-tile gather + image/state outputs
+        "k_render_bwd": HW * 32 + R * 44 + P * 44,        # pixel grads/state read + gather + intermediate grads write
+        "k_preprocess_bwd": P * 44 + P * (80 + S) + P * (68 + S),
+    }
+    total = P * (352 + 3 * S) + R * 120 + HW * 60
+    return per_kernel, total
+
+
+def cpu_baseline(cfg, n_sample_views):
+    """C oracle (oracle/raster_oracle.c), OpenMP over all host cores, fwd+bwd on a bounded sample of the workload."""
+    from oracle import c_oracle as CO
+    from topo4d_amd import boundary, scene
+    CO.build()
+    params = scene.make_gaussians(cfg["n_lat"], cfg["n_lon"], opacity="A", sh_degree=cfg["sh_degree"], seed=0)
+    rv = {k: v.detach() for k, v in boundary.params2rendervar(params).items()}
+    if cfg["sh_degree"] is not None:
+        rv["shs"] = params["shs"]
+        rv.pop("colors_precomp")
+    cams = scene.camera_rig(cfg["H"], cfg["W"], n_views=cfg["n_views"], true_campos=cfg["sh_degree"] is not None)
+    if cfg["sh_degree"] is not None:
+        cams = [c._replace(sh_degree=cfg["sh_degree"]) for c in cams]
+    dc, _, _ = scene.output_cotangents(n_sample_views, cfg["H"], cfg["W"], seed=0)
+    # warm-up (page-in, OpenMP pool)
+    r = CO.OracleRender(cams[0], rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                        rv.get("colors_precomp"), rv.get("shs"))
+    r.backward(dc[0])
+    t0 = time.perf_counter()
+    for v in range(n_sample_views):
+        r = CO.OracleRender(cams[v % len(cams)], rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                            rv.get("colors_precomp"), rv.get("shs"))
+        r.backward(dc[v])
+    dt = time.perf_counter() - t0
+    return {"value": round(n_sample_views / dt, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_sample_views} of the {cfg['n_views']} views of the same scene, fwd+bwd, "
+                      f"oracle/raster_oracle.c -O3 -fopenmp ({os.cpu_count()} threads), {dt:.1f}s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2", choices=["C2", "C4"])
+    ap.add_argument("--opacity", default="A", choices=["A", "B"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-views", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists by design)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import topo4d_amd
+    from topo4d_amd import ViewBatch, _lib, boundary, dist as t4d_dist, pack_views, scene
+
+    cfg = dict(scene.CONFIGS[args.config])
+    H, W, V = cfg["H"], cfg["W"], cfg["n_views"]
+    params = scene.make_gaussians(cfg["n_lat"], cfg["n_lon"], opacity=args.opacity, sh_degree=cfg["sh_degree"], seed=0)
+    P = params["means3D"].shape[0]
+    base_means = params["means3D"].clone()
+    cams = scene.camera_rig(H, W, n_views=V, device=dev, true_campos=cfg["sh_degree"] is not None)
+    if cfg["sh_degree"] is not None:
+        cams = [c._replace(sh_degree=cfg["sh_degree"]) for c in cams]
+    views = pack_views(cams, dev)
+    dc, _, _ = scene.output_cotangents(V, H, W, seed=0)
+    dc = dc.to(dev)
+
+    # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
+    n_frames = 64
+    my_frames = t4d_dist.shard_units(n_frames, rank, world)
+    rv_frames = []
+    for t in my_frames[: max(1, min(len(my_frames), 8))]:
+        p = dict(params)
+        p["means3D"] = scene.frame_displacement(base_means, t, n_frames)
+        rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
+        if cfg["sh_degree"] is not None:
+            rv["shs"] = params["shs"].to(dev)
+            rv.pop("colors_precomp")
+        rv_frames.append(rv)
+
+    batch = ViewBatch(views, H, W, 1.0, cfg["sh_degree"] or 0)
+    losses = torch.zeros(V, device=dev)
+
+    def step(i):
+        rv = rv_frames[i % len(rv_frames)]
+        color, radii, depth, alpha = batch.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                                                   rv.get("colors_precomp"), rv.get("shs"))
+        g = batch.backward(dc)
+        torch.mul(color, dc).sum(dim=(1, 2, 3), out=losses)     # per-view scalar "photometric" loss
+        if world > 1:
+            return t4d_dist.gather_losses(losses), g
+        return losses, g
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    # warm-up: first call is "checked" (learns the pair-arena capacity), the rest of the run is lazy (no host sync)
+    topo4d_amd.set_sync_mode("checked")
+    step(0)
+    st0 = batch.fetch_status()
+    for i in range(len(rv_frames)):
+        step(i)
+    topo4d_amd.set_sync_mode("lazy")
+    for i in range(args.warmup):
+        step(i)
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    st = batch.fetch_status()
+    if st.overflow:
+        raise SystemExit("pair arena overflowed during the timed region: result invalid")
+
+    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+
+    # ---- per-kernel durations with HIP events (same steps again; keeps `value` free of event overhead) ----
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        torch.cuda.synchronize(dev)
+        _lib.profile_begin()
+        tp0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize(dev)
+        tp = time.perf_counter() - tp0
+        prof = _lib.profile_end()
+        R_view = st.total_pairs / V
+        S = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
+        per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, S)
+        for name, (ms, n) in prof.items():
+            if n:
+                kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": n,
+                                 "alg_GBs": round(per_kernel[name] * V / (1e-3 * ms / n) / 1e9, 1)}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+        ach = per_kernel[dom] * V / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.config, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "alg_bytes_per_launch": int(per_kernel[dom] * V), "avg_us": kernels[dom]["avg_us"],
+                    "pairs_per_view": int(R_view), "ms_per_step_profiled": round(1e3 * tp / args.steps, 4),
+                    "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels}
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(device_ids=[local_rank])
+
+    if rank == 0:
+        views_total = V * args.steps * world
+        value = views_total / dt
+        _, total_bytes = algorithmic_bytes(P, st.total_pairs / V, H * W,
+                                           0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4)
+        if roofline is not None:
+            roofline["pipeline_frac_of_peak"] = round(value / world * total_bytes / 1e9 / PEAK_HBM_GBS, 4)
+            roofline["pipeline_frac_of_achievable"] = round(value / world * total_bytes / 1e9 / ACHIEVABLE_HBM_GBS, 4)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            n_s = args.cpu_sample_views or (8 if args.config == "C2" else 2)
+            try:
+                cpu = cpu_baseline(cfg, n_s)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                cpu = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        out = {
+            "metric": "rasterizer fwd+bwd views/sec", "value": round(value, 2), "unit": "views/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {V} views x {H}x{W}, P={P} vertex-bound Gaussians, "
+                                   f"{'SH degree %d' % cfg['sh_degree'] if cfg['sh_degree'] is not None else 'precomputed RGB'}, "
+                                   f"opacity scenario {args.opacity}, forward+backward, per-view gradients",
+                       "views_per_step_per_gpu": V, "frames": n_frames, "parallelism": f"frame-sharded x{world}",
+                       "sync_mode": "lazy (capacity learned by checked warm-up)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,26 @@ int t4d_fetch_status(const T4DProblem *prob, const void *state, T4DStatus *out, 
 /* present[i] = 1 iff Gaussian i passes the near-plane test of view record `view` (upstream markVisible). */
 int t4d_mark_visible(int32_t P, const float *means3D, const float *view, uint8_t *present, void *hip_stream);
 
+/* Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on.  Between
+ * t4d_profile_begin() and t4d_profile_end() every kernel launch of this library is bracketed by two events;
+ * t4d_profile_end() synchronises them and returns, per kernel, the summed elapsed time and the launch count.
+ * bench.py uses this for the `roofline` object (duration of the dominant kernel).  Not thread-safe. */
+typedef struct T4DKernelTime {
+    const char *name;
+    double total_ms;
+    int64_t launches;
+} T4DKernelTime;
+int t4d_profile_begin(void);
+int t4d_profile_end(T4DKernelTime *out, int max_entries, int *n_entries);
+
+/* Test/debug only: byte offsets of the arrays inside a state buffer, in this order:
+ *   status, view_total, view_cursor, tile_count, tile_cursor, tile_off, xy, depth, conic_opacity, rgb, clamped,
+ *   pair_off, keys, final_T, n_contrib, total_bytes.
+ * The layout is NOT part of the stable ABI; tests use it to check the integer state (tile bins, sort order,
+ * n_contrib) bit-for-bit against the oracle. */
+#define T4D_DEBUG_LAYOUT_FIELDS 16
+int t4d_debug_state_layout(const T4DProblem *prob, int has_sh, uint64_t *offsets, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_PREFILTERED = 1, 2, 4
 EXPORTS = (
     "t4d_abi_version", "t4d_last_error", "t4d_state_bytes", "t4d_backward_scratch_bytes",
     "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
+    "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end",
 )
 
 
@@ -52,6 +53,10 @@ class T4DBackwardIO(C.Structure):
             "dL_dcolor", "dL_ddepth", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dshs",
             "dL_dopacities", "dL_dscales", "dL_drotations", "dL_dcov3D", "scratch")] + [
                 ("scratch_bytes", C.c_size_t)]
+
+
+class T4DKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_int64)]
 
 
 class ExtensionMissing(RuntimeError):
@@ -89,10 +94,29 @@ def load():
     lib.t4d_fetch_status.argtypes = [C.POINTER(T4DProblem), C.c_void_p, C.POINTER(T4DStatus), C.c_void_p]
     lib.t4d_mark_visible.restype = C.c_int
     lib.t4d_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t4d_debug_state_layout.restype = C.c_int
+    lib.t4d_debug_state_layout.argtypes = [C.POINTER(T4DProblem), C.c_int, C.POINTER(C.c_uint64), C.c_int]
+    lib.t4d_profile_begin.restype = C.c_int
+    lib.t4d_profile_end.restype = C.c_int
+    lib.t4d_profile_end.argtypes = [C.POINTER(T4DKernelTime), C.c_int, C.POINTER(C.c_int)]
     if lib.t4d_abi_version() != T4D_ABI_VERSION:
         raise ExtensionMissing(f"ABI mismatch: library {lib.t4d_abi_version()} vs python {T4D_ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+def profile_begin() -> None:
+    load().t4d_profile_begin()
+
+
+def profile_end() -> dict:
+    """{kernel name: (total_ms, launches)} since profile_begin()."""
+    arr = (T4DKernelTime * 16)()
+    n = C.c_int(0)
+    rc = load().t4d_profile_end(arr, 16, C.byref(n))
+    if rc != T4D_OK:
+        raise RuntimeError(f"t4d_profile_end failed: {last_error()}")
+    return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n.value)}
 
 
 def last_error() -> str:

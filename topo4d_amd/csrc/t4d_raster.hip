@@ -1,0 +1,1231 @@
+// t4d_raster.hip — MI355X (gfx950 / CDNA4) differentiable Gaussian-splatting rasterizer + C ABI.
+//
+// Replaces, for Topo4D, the un-vendored CUDA package `diff_gaussian_rasterization` that the reference calls at
+// train.py:307,388,463,484 (boundary: helpers.py:63-112).  Written from the published algorithm (SURVEY.md
+// Appendix A) for wave64 / LDS / 8-XCD hardware; it is not a translation of the CUDA sources (which are not
+// even present under /root/reference).  Differences in STRUCTURE from upstream, all result-preserving:
+//   * V views of the same Gaussians go through one set of launches (blockIdx.z / .y = view);
+//   * binning is count -> per-view tile scan -> scatter into per-tile bins -> per-tile LDS bitonic sort on the
+//     64-bit key (depth bits << 32 | Gaussian index).  That reproduces upstream's order (stable radix sort on
+//     tile|depth of pairs emitted in index order) without a global sort and without a host round trip;
+//   * the backward never uses global atomics: each tile writes one partial-gradient record per (Gaussian,tile)
+//     pair after a wave64 DPP reduction + fixed-order cross-wave sum, and the per-Gaussian kernel gathers its
+//     pairs in fixed order.  Gradients are bit-reproducible run to run.
+//
+// Kernels (DESIGN.md has the bytes/roofline of each):
+//   k_preprocess      A.1  per (view,Gaussian): cull, project, cov3D, EWA cov2D, conic, radius, tile rect, SH colour;
+//                          + per-tile counts (atomics) + pair-slot allocation (one returning atomic per workgroup)
+//   k_scan_tiles      A.2  per view: exclusive scan of tile counts -> tile offsets, overflow status
+//   k_scatter         A.2  per (view,Gaussian): emit key into each touched tile's bin
+//   k_sort_tiles      A.2  per (view,tile): sort the bin by (depth bits, index)
+//   k_render_fwd      A.3  per (view,tile): 256 threads = 4 wave64, each wave an 8x8 pixel block; front-to-back blend
+//   k_render_bwd      A.4  per (view,tile): back-to-front replay, wave64 reduction, one record per pair
+//   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D/SH chain rule
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/t4d_config.h"
+#include "../../include/topo4d_raster.h"
+
+#define T4D_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave64)
+constexpr int kFwdBatch = 256;       // splats staged in LDS per round of the forward blend
+constexpr int kBwdBatch = 128;       // splats staged per round of the backward replay
+constexpr int kSortLdsCap = 4096;    // keys sorted in LDS (32 KiB); longer bins use the global-memory path
+constexpr int kGP = T4D_GRAD_PAIR_FLOATS;
+
+thread_local char g_err[512] = "";
+
+// optional per-kernel timing with HIP events (t4d_profile_begin/end); used by bench.py for the roofline object
+enum KernelId { K_PREPROCESS = 0, K_SCAN_TILES, K_SCATTER, K_SORT_TILES, K_RENDER_FWD, K_RENDER_BWD, K_PREPROCESS_BWD, K_COUNT };
+const char *const kKernelNames[K_COUNT] = { "k_preprocess", "k_scan_tiles", "k_scatter", "k_sort_tiles", "k_render_fwd",
+                                            "k_render_bwd", "k_preprocess_bwd" };
+struct ProfRec { int id; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+// ---------------------------------------------------------------------------------------------------------
+// state / scratch layout
+// ---------------------------------------------------------------------------------------------------------
+struct Layout {
+    size_t status, view_total, view_cursor, tile_count, tile_cursor, zero_end;
+    size_t tile_off, xy, depth, conic_opacity, rgb, clamped, pair_off, keys, final_T, n_contrib, total;
+};
+
+struct DevStatus {            // first bytes of the state buffer
+    uint32_t overflow;
+    uint32_t max_pairs;
+    unsigned long long total_pairs;
+};
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+Layout make_layout(const T4DProblem &p)
+{
+    Layout L;
+    const size_t V = (size_t)p.n_views, P = (size_t)p.P;
+    const size_t T = (size_t)((p.W + T4D_TILE_X - 1) / T4D_TILE_X) * (size_t)((p.H + T4D_TILE_Y - 1) / T4D_TILE_Y);
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t cap = (size_t)p.pair_capacity;
+    size_t o = 0;
+    L.status = o;        o = align_up(o + sizeof(DevStatus));
+    L.view_total = o;    o = align_up(o + V * 4);
+    L.view_cursor = o;   o = align_up(o + V * 4);
+    L.tile_count = o;    o = align_up(o + V * T * 4);
+    L.tile_cursor = o;   o = align_up(o + V * T * 4);
+    L.zero_end = o;
+    L.tile_off = o;      o = align_up(o + V * T * 4);
+    L.xy = o;            o = align_up(o + V * P * 8);
+    L.depth = o;         o = align_up(o + V * P * 4);
+    L.conic_opacity = o; o = align_up(o + V * P * 16);
+    L.rgb = o;           o = align_up(o + (p.sh_coeffs > 0 ? V * P * 12 : 0));
+    L.clamped = o;       o = align_up(o + (p.sh_coeffs > 0 ? V * P : 0));
+    L.pair_off = o;      o = align_up(o + V * P * 4);
+    L.keys = o;          o = align_up(o + V * cap * 8);
+    L.final_T = o;       o = align_up(o + V * HW * 4);
+    L.n_contrib = o;     o = align_up(o + V * HW * 4);
+    L.total = o;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel parameter block (passed by value)
+// ---------------------------------------------------------------------------------------------------------
+struct KP {
+    int V, P, H, W, gx, gy, T, deg, M;
+    float scale_modifier;
+    uint32_t cap;
+    const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
+    // state
+    DevStatus *status;
+    uint32_t *view_total, *view_cursor, *tile_count, *tile_cursor, *tile_off, *pair_off;
+    float2 *xy;
+    float *depth;
+    float4 *conic_opacity;
+    float *rgb;
+    uint8_t *clamped;
+    unsigned long long *keys;
+    float *final_T;
+    uint32_t *n_contrib;
+    // forward outputs
+    float *out_color, *out_depth, *out_alpha;
+    int32_t *radii;
+    // backward
+    const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
+    float *grad_pair;
+    float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dshs, *dL_dopacities, *dL_dscales, *dL_drotations, *dL_dcov3D;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * S - 1.0f) * 0.5f; }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
+{
+    x0 = min(gx, max(0, (int)((px - r) / T4D_TILE_X)));
+    y0 = min(gy, max(0, (int)((py - r) / T4D_TILE_Y)));
+    x1 = min(gx, max(0, (int)((px + r + T4D_TILE_X - 1) / T4D_TILE_X)));
+    y1 = min(gy, max(0, (int)((py + r + T4D_TILE_Y - 1) / T4D_TILE_Y)));
+}
+
+// wave64 inclusive prefix sum (uint32)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// DPP move helper: returns src permuted by CTRL; lanes/rows disabled by the masks read 0.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp0(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+
+// wave64 sum; the total is valid in lane 63 (CDNA row/bcast DPP: 6 v_add_f32_dpp, no LDS traffic)
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v += dpp0<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp0<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp0<0x141>(v);         // row_half_mirror
+    v += dpp0<0x140>(v);         // row_mirror         -> every lane holds its 16-lane row sum
+    v += dpp0<0x142, 0xA>(v);    // row_bcast15 into rows 1,3
+    v += dpp0<0x143, 0xC>(v);    // row_bcast31 into rows 2,3 -> lane 63 = wave sum
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+// un-normalised quaternion (r,x,y,z) -> rotation, row-major (same matrix as reference external.py:26-43)
+__device__ __forceinline__ void quat_rot(const float4 q, float R[9])
+{
+#pragma clang fp contract(off)
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z);       R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float *scale, float mod, const float4 q, float cov[6])
+{
+#pragma clang fp contract(off)
+    float R[9], M[9];
+    quat_rot(q, R);
+    const float s[3] = { mod * scale[0], mod * scale[1], mod * scale[2] };
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[i * 3 + k] = R[i * 3 + k] * s[k];
+    cov[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    cov[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    cov[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    cov[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    cov[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    cov[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+}
+
+// rows T0,T1 of T = J*W of the EWA projection; t = clamped view-space point; in-range flags of the clamp
+__device__ __forceinline__ void ewa_rows(const float *mean, const float *view, float fx, float fy, float tanx, float tany,
+                                         float T0[3], float T1[3], float t[3], bool &inx, bool &iny)
+{
+#pragma clang fp contract(off)
+    t[0] = view[0] * mean[0] + view[4] * mean[1] + view[8] * mean[2] + view[12];
+    t[1] = view[1] * mean[0] + view[5] * mean[1] + view[9] * mean[2] + view[13];
+    t[2] = view[2] * mean[0] + view[6] * mean[1] + view[10] * mean[2] + view[14];
+    const float limx = T4D_FRUSTUM_CLAMP * tanx, limy = T4D_FRUSTUM_CLAMP * tany;
+    const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    inx = !(txtz < -limx || txtz > limx);
+    iny = !(tytz < -limy || tytz > limy);
+    t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    const float J00 = fx / t[2], J02 = -(fx * t[0]) / (t[2] * t[2]);
+    const float J11 = fy / t[2], J12 = -(fy * t[1]) / (t[2] * t[2]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        T0[j] = J00 * view[j * 4 + 0] + J02 * view[j * 4 + 2];
+        T1[j] = J11 * view[j * 4 + 1] + J12 * view[j * 4 + 2];
+    }
+}
+
+__device__ __forceinline__ void sym3_mul(const float c[6], const float v[3], float o[3])
+{
+#pragma clang fp contract(off)
+    o[0] = c[0] * v[0] + c[1] * v[1] + c[2] * v[2];
+    o[1] = c[1] * v[0] + c[3] * v[1] + c[4] * v[2];
+    o[2] = c[2] * v[0] + c[4] * v[1] + c[5] * v[2];
+}
+
+__device__ __forceinline__ void sh_basis(int deg, const float d[3], float b[16])
+{
+#pragma clang fp contract(off)
+    const float x = d[0], y = d[1], z = d[2];
+    b[0] = T4D_SH_C0;
+    if (deg > 0) {
+        b[1] = -T4D_SH_C1 * y; b[2] = T4D_SH_C1 * z; b[3] = -T4D_SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = T4D_SH_C2_0 * xy; b[5] = T4D_SH_C2_1 * yz; b[6] = T4D_SH_C2_2 * (2.f * zz - xx - yy);
+            b[7] = T4D_SH_C2_3 * xz; b[8] = T4D_SH_C2_4 * (xx - yy);
+            if (deg > 2) {
+                b[9] = T4D_SH_C3_0 * y * (3.f * xx - yy);
+                b[10] = T4D_SH_C3_1 * xy * z;
+                b[11] = T4D_SH_C3_2 * y * (4.f * zz - xx - yy);
+                b[12] = T4D_SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = T4D_SH_C3_4 * x * (4.f * zz - xx - yy);
+                b[14] = T4D_SH_C3_5 * z * (xx - yy);
+                b[15] = T4D_SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float bx[16], float by[16], float bz[16])
+{
+    const float x = d[0], y = d[1], z = d[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) bx[k] = by[k] = bz[k] = 0.f;
+    if (deg > 0) {
+        by[1] = -T4D_SH_C1; bz[2] = T4D_SH_C1; bx[3] = -T4D_SH_C1;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            bx[4] = T4D_SH_C2_0 * y; by[4] = T4D_SH_C2_0 * x;
+            by[5] = T4D_SH_C2_1 * z; bz[5] = T4D_SH_C2_1 * y;
+            bx[6] = T4D_SH_C2_2 * -2.f * x; by[6] = T4D_SH_C2_2 * -2.f * y; bz[6] = T4D_SH_C2_2 * 4.f * z;
+            bx[7] = T4D_SH_C2_3 * z; bz[7] = T4D_SH_C2_3 * x;
+            bx[8] = T4D_SH_C2_4 * 2.f * x; by[8] = T4D_SH_C2_4 * -2.f * y;
+            if (deg > 2) {
+                bx[9] = T4D_SH_C3_0 * 6.f * x * y;             by[9] = T4D_SH_C3_0 * (3.f * xx - 3.f * yy);
+                bx[10] = T4D_SH_C3_1 * y * z;                  by[10] = T4D_SH_C3_1 * x * z;   bz[10] = T4D_SH_C3_1 * x * y;
+                bx[11] = T4D_SH_C3_2 * -2.f * x * y;           by[11] = T4D_SH_C3_2 * (4.f * zz - xx - 3.f * yy);
+                bz[11] = T4D_SH_C3_2 * 8.f * y * z;
+                bx[12] = T4D_SH_C3_3 * -6.f * x * z;           by[12] = T4D_SH_C3_3 * -6.f * y * z;
+                bz[12] = T4D_SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+                bx[13] = T4D_SH_C3_4 * (4.f * zz - 3.f * xx - yy); by[13] = T4D_SH_C3_4 * -2.f * x * y;
+                bz[13] = T4D_SH_C3_4 * 8.f * x * z;
+                bx[14] = T4D_SH_C3_5 * 2.f * x * z;            by[14] = T4D_SH_C3_5 * -2.f * y * z;
+                bz[14] = T4D_SH_C3_5 * (xx - yy);
+                bx[15] = T4D_SH_C3_6 * (3.f * xx - 3.f * yy);  by[15] = T4D_SH_C3_6 * -6.f * x * y;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.1 preprocess (+ tile counting + pair-slot allocation)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
+{
+#pragma clang fp contract(off)
+    __shared__ uint32_t s_wave_tot[4];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x * kBlock + tid;
+    const int v = blockIdx.y;
+    const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+    const float *view = vr, *proj = vr + 16;
+    const size_t vg = (size_t)v * kp.P + g;
+
+    uint32_t tiles = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (g < kp.P) {
+        const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+        int radius = 0;
+        const float pvz = view[2] * mean[0] + view[6] * mean[1] + view[10] * mean[2] + view[14];
+        if (pvz > T4D_NEAR_CULL_Z) {
+            const float hx = proj[0] * mean[0] + proj[4] * mean[1] + proj[8] * mean[2] + proj[12];
+            const float hy = proj[1] * mean[0] + proj[5] * mean[1] + proj[9] * mean[2] + proj[13];
+            const float hw = proj[3] * mean[0] + proj[7] * mean[1] + proj[11] * mean[2] + proj[15];
+            const float pw = 1.0f / (hw + T4D_HOM_W_EPS);
+            float cov3[6];
+            if (kp.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov3[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+            } else {
+                const float sc[3] = { kp.scales[3 * (size_t)g], kp.scales[3 * (size_t)g + 1], kp.scales[3 * (size_t)g + 2] };
+                const float4 q = reinterpret_cast<const float4 *>(kp.rotations)[g];
+                cov3d_from_scale_rot(sc, kp.scale_modifier, q, cov3);
+            }
+            const float tanx = vr[38], tany = vr[39];
+            const float fx = kp.W / (2.0f * tanx), fy = kp.H / (2.0f * tany);
+            float T0[3], T1[3], t[3];
+            bool inx, iny;
+            ewa_rows(mean, view, fx, fy, tanx, tany, T0, T1, t, inx, iny);
+            float v0[3], v1[3];
+            sym3_mul(cov3, T0, v0);
+            sym3_mul(cov3, T1, v1);
+            const float a = T0[0] * v0[0] + T0[1] * v0[1] + T0[2] * v0[2] + T4D_COV2D_DILATION;
+            const float b = T0[0] * v1[0] + T0[1] * v1[1] + T0[2] * v1[2];
+            const float c = T1[0] * v1[0] + T1[1] * v1[1] + T1[2] * v1[2] + T4D_COV2D_DILATION;
+            const float det = a * c - b * b;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float mid = 0.5f * (a + c);
+                const float l1 = mid + sqrtf(fmaxf(T4D_EIGEN_FLOOR, mid * mid - det));
+                const float l2 = mid - sqrtf(fmaxf(T4D_EIGEN_FLOOR, mid * mid - det));
+                const float my_radius = ceilf(T4D_RADIUS_SIGMAS * sqrtf(fmaxf(l1, l2)));
+                const float px = ndc2pix(hx * pw, kp.W), py = ndc2pix(hy * pw, kp.H);
+                tile_rect(px, py, (int)my_radius, kp.gx, kp.gy, x0, y0, x1, y1);
+                tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+                if (tiles > 0) {
+                    radius = (int)my_radius;
+                    kp.xy[vg] = make_float2(px, py);
+                    kp.depth[vg] = pvz;
+                    kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, kp.opacities[g]);
+                    if (kp.shs) {
+                        float d[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
+                        const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                        d[0] /= len; d[1] /= len; d[2] /= len;
+                        float bas[16];
+                        sh_basis(kp.deg, d, bas);
+                        const int K = (kp.deg + 1) * (kp.deg + 1);
+                        const float *sh = kp.shs + (size_t)g * kp.M * 3;
+                        uint32_t cl = 0;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            float r = 0.f;
+                            for (int k = 0; k < K; k++) r += bas[k] * sh[k * 3 + ch];
+                            r += 0.5f;
+                            if (r < 0.f) cl |= 1u << ch;
+                            kp.rgb[vg * 3 + ch] = fmaxf(r, 0.f);
+                        }
+                        kp.clamped[vg] = (uint8_t)cl;
+                    }
+                }
+            }
+        }
+        kp.radii[vg] = radius;
+    }
+
+    // pair-slot allocation: block-local exclusive scan, ONE returning atomic per workgroup on the view's cursor
+    const uint32_t incl = wave_incl_scan(tiles);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, block_tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t t = s_wave_tot[w];
+        if (w < wave) wave_off += t;
+        block_tot += t;
+    }
+    if (tid == 0) s_base = block_tot ? atomicAdd(&kp.view_cursor[v], block_tot) : 0u;
+    __syncthreads();
+    if (g < kp.P) kp.pair_off[vg] = s_base + wave_off + incl - tiles;
+
+    // per-tile counts
+    if (tiles) {
+        uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&cnt[y * kp.gx + x], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.2 per-view exclusive scan of tile counts
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
+{
+    __shared__ uint32_t s_wave_tot[16];
+    __shared__ uint32_t s_carry;
+    const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
+    uint32_t *off = kp.tile_off + (size_t)v * kp.T;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < kp.T; base += 1024) {
+        const int t = base + tid;
+        const uint32_t c = t < kp.T ? cnt[t] : 0u;
+        const uint32_t incl = wave_incl_scan(c);
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t x = s_wave_tot[w];
+            if (w < wave) woff += x;
+            tot += x;
+        }
+        const uint32_t carry = s_carry;
+        if (t < kp.T) off[t] = carry + woff + incl - c;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = s_carry;
+        kp.view_total[v] = total;
+        atomicMax(&kp.status->max_pairs, total);
+        atomicAdd(&kp.status->total_pairs, (unsigned long long)total);
+        if (total > kp.cap) atomicOr(&kp.status->overflow, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.2 scatter keys into tile bins
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
+{
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= kp.P) return;
+    const size_t vg = (size_t)v * kp.P + g;
+    const int r = kp.radii[vg];
+    if (r <= 0) return;
+    const float2 p = kp.xy[vg];
+    int x0, y0, x1, y1;
+    tile_rect(p.x, p.y, r, kp.gx, kp.gy, x0, y0, x1, y1);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(kp.depth[vg]) << 32) | (uint32_t)g;
+    uint32_t *cur = kp.tile_cursor + (size_t)v * kp.T;
+    const uint32_t *off = kp.tile_off + (size_t)v * kp.T;
+    unsigned long long *keys = kp.keys + (size_t)v * kp.cap;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const int t = y * kp.gx + x;
+            const uint32_t pos = off[t] + atomicAdd(&cur[t], 1u);
+            if (pos < kp.cap) keys[pos] = key;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.2 per-tile sort by (depth bits, Gaussian index): all-ascending bitonic network for arbitrary n
+// ---------------------------------------------------------------------------------------------------------
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_any_n(Ptr a, const uint32_t n, const int tid)
+{
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const uint32_t half = np2 >> 1;
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        // flip stage: i <-> block_end - 1 - (i - block_start)
+        for (uint32_t p = tid; p < half; p += kBlock) {
+            const uint32_t hb = k >> 1;
+            const uint32_t blk = p / hb, o = p - blk * hb;
+            const uint32_t i = blk * k + o, j = blk * k + k - 1 - o;
+            if (j < n) {
+                const unsigned long long x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = k >> 2; s > 0; s >>= 1) {
+            for (uint32_t p = tid; p < half; p += kBlock) {
+                const uint32_t i = ((p & ~(s - 1)) << 1) | (p & (s - 1));
+                const uint32_t j = i | s;
+                if (j < n) {
+                    const unsigned long long x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
+{
+    __shared__ unsigned long long s_keys[kSortLdsCap];
+    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const size_t vt = (size_t)v * kp.T + t;
+    const uint32_t off = kp.tile_off[vt];
+    uint32_t n = kp.tile_count[vt];
+    if (off >= kp.cap) return;
+    n = min(n, kp.cap - off);
+    if (n < 2) return;
+    unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+    if (n <= (uint32_t)kSortLdsCap) {
+        for (uint32_t i = tid; i < n; i += kBlock) s_keys[i] = keys[i];
+        __syncthreads();
+        bitonic_any_n(s_keys, n, tid);
+        for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
+    } else {
+        // rare: a bin longer than the LDS buffer is sorted in place in global memory by this workgroup
+        // (same network; __syncthreads() orders the workgroup's own global accesses through its CU's L1/L2)
+        bitonic_any_n(keys, n, tid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.3 forward blend.  Workgroup = 16x16 tile; wave w owns the 8x8 block (w&1, w>>1), lane l pixel (l&7, l>>3).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_pixel(int tid, int tx, int ty, int &px, int &py)
+{
+    const int w = tid >> 6, l = tid & 63;
+    px = tx * T4D_TILE_X + ((w & 1) << 3) + (l & 7);
+    py = ty * T4D_TILE_Y + ((w >> 1) << 3) + (l >> 3);
+}
+
+__global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
+{
+    __shared__ float2 s_xy[kFwdBatch];
+    __shared__ float4 s_co[kFwdBatch];
+    __shared__ float4 s_cd[kFwdBatch];   // rgb + depth
+    const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const size_t vt = (size_t)v * kp.T + (size_t)ty * kp.gx + tx;
+    const uint32_t off = kp.tile_off[vt];
+    uint32_t n = kp.tile_count[vt];
+    n = off >= kp.cap ? 0u : min(n, kp.cap - off);
+    const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+    const float2 *xy = kp.xy + (size_t)v * kp.P;
+    const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
+    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
+
+    int px, py;
+    tile_pixel(tid, tx, ty, px, py);
+    const bool inside = px < kp.W && py < kp.H;
+    const float pxf = (float)px, pyf = (float)py;
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, D = 0.f;
+    uint32_t contributor = 0, last_contributor = 0;
+
+    for (uint32_t b = 0; b < n; b += kFwdBatch) {
+        if (__syncthreads_count(done) == kBlock) break;
+        if (b + tid < n) {
+            const unsigned long long key = keys[b + tid];
+            const uint32_t g = (uint32_t)key;
+            s_xy[tid] = xy[g];
+            s_co[tid] = co[g];
+            s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
+                                    __uint_as_float((uint32_t)(key >> 32)));
+        }
+        __syncthreads();
+        const int cnt = (int)min((uint32_t)kFwdBatch, n - b);
+        for (int j = 0; !done && j < cnt; j++) {
+            contributor++;
+            const float2 g_xy = s_xy[j];
+            const float dx = g_xy.x - pxf, dy = g_xy.y - pyf;
+            const float4 c = s_co[j];
+            const float power = -0.5f * (c.x * dx * dx + c.z * dy * dy) - c.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(T4D_ALPHA_MAX, c.w * expf(power));
+            if (alpha < T4D_ALPHA_MIN) continue;
+            const float test_T = T * (1.f - alpha);
+            if (test_T < T4D_T_STOP) { done = true; continue; }
+            const float4 cd = s_cd[j];
+            const float w = alpha * T;
+            C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
+            Wt += w;
+            D += cd.w * w;
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (inside) {
+        const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+        const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
+        kp.final_T[(size_t)v * HW + pix] = T;
+        kp.n_contrib[(size_t)v * HW + pix] = last_contributor;
+        float *oc = kp.out_color + (size_t)v * 3 * HW;
+        oc[pix] = C0 + T * vr[35];
+        oc[HW + pix] = C1 + T * vr[36];
+        oc[2 * HW + pix] = C2 + T * vr[37];
+        kp.out_depth[(size_t)v * HW + pix] = D;
+        kp.out_alpha[(size_t)v * HW + pix] = Wt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.4 backward replay.  No global atomics: one kGP-float record per (Gaussian,tile) pair.
+// record: [0,1] d/d(ndc xy)  [2,3,4] d/d(conic A,B,C)  [5] d/d opacity  [6,7,8] d/d rgb  [9] d/d depth
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
+{
+    __shared__ float2 s_xy[kBwdBatch];
+    __shared__ float4 s_co[kBwdBatch];
+    __shared__ float4 s_cd[kBwdBatch];
+    __shared__ uint32_t s_pair[kBwdBatch];
+    __shared__ float4 s_acc[4][kBwdBatch][3];
+    __shared__ unsigned long long s_mask[4][kBwdBatch / 64];
+    __shared__ uint32_t s_wmax[4];
+
+    const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const size_t vt = (size_t)v * kp.T + (size_t)ty * kp.gx + tx;
+    const uint32_t off = kp.tile_off[vt];
+    uint32_t n = kp.tile_count[vt];
+    n = off >= kp.cap ? 0u : min(n, kp.cap - off);
+    if (n == 0) return;
+    const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+    const float2 *xy = kp.xy + (size_t)v * kp.P;
+    const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
+    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
+    const int32_t *radii = kp.radii + (size_t)v * kp.P;
+    const uint32_t *pair_off = kp.pair_off + (size_t)v * kp.P;
+    float4 *grad_pair = reinterpret_cast<float4 *>(kp.grad_pair) + (size_t)v * kp.cap * 3;
+    const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+
+    int px, py;
+    tile_pixel(tid, tx, ty, px, py);
+    const bool inside = px < kp.W && py < kp.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
+
+    float T_final = 0.f, dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f, dalp = 0.f;
+    uint32_t last_contributor = 0;
+    if (inside) {
+        T_final = kp.final_T[(size_t)v * HW + pix];
+        last_contributor = kp.n_contrib[(size_t)v * HW + pix];
+        const float *dc = kp.dL_dcolor + (size_t)v * 3 * HW;
+        dp0 = dc[pix]; dp1 = dc[HW + pix]; dp2 = dc[2 * HW + pix];
+        if (kp.dL_ddepth) ddep = kp.dL_ddepth[(size_t)v * HW + pix];
+        if (kp.dL_dalpha) dalp = kp.dL_dalpha[(size_t)v * HW + pix];
+    }
+    float T = T_final;
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    float adr = 0.f, ldp = 0.f, aar = 0.f, last_alpha = 0.f;
+    const float bg_dot = vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2;
+    const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
+
+    const uint32_t wave_max = wave_max_u32(last_contributor);
+    if (lane == 0) s_wmax[wave] = wave_max;
+    __syncthreads();
+    const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+
+    const int nb = (int)((n + kBwdBatch - 1) / kBwdBatch);
+    for (int bi = nb - 1; bi >= 0; bi--) {
+        const uint32_t lo = (uint32_t)bi * kBwdBatch;
+        const int cnt = (int)min((uint32_t)kBwdBatch, n - lo);
+        const bool live = lo < tile_max;      // workgroup-uniform
+        // ---- stage ----
+        if (tid < cnt) {
+            const unsigned long long key = keys[lo + tid];
+            const uint32_t g = (uint32_t)key;
+            const float2 p = xy[g];
+            int x0, y0, x1, y1;
+            tile_rect(p.x, p.y, radii[g], kp.gx, kp.gy, x0, y0, x1, y1);
+            s_pair[tid] = pair_off[g] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            if (live) {
+                s_xy[tid] = p;
+                s_co[tid] = co[g];
+                s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
+                                        __uint_as_float((uint32_t)(key >> 32)));
+            }
+        }
+        __syncthreads();
+        unsigned long long m0 = 0ull, m1 = 0ull;
+        if (live) {
+            for (int j = cnt - 1; j >= 0; j--) {
+                const uint32_t pos = lo + (uint32_t)j;
+                if (pos >= wave_max) continue;                 // wave-uniform
+                bool contrib = pos < last_contributor;
+                const float2 g_xy = s_xy[j];
+                const float dx = g_xy.x - pxf, dy = g_xy.y - pyf;
+                const float4 c = s_co[j];
+                const float power = -0.5f * (c.x * dx * dx + c.z * dy * dy) - c.y * dx * dy;
+                const float G = expf(power);
+                const float alpha = fminf(T4D_ALPHA_MAX, c.w * G);
+                contrib = contrib && !(power > 0.0f) && !(alpha < T4D_ALPHA_MIN);
+                if (!__any(contrib)) continue;                 // wave-uniform
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f, r8 = 0.f, r9 = 0.f;
+                if (contrib) {
+                    const float4 cd = s_cd[j];
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha;
+                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = cd.x;
+                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = cd.y;
+                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = cd.z;
+                    dL_dalpha = (cd.x - ar0) * dp0 + (cd.y - ar1) * dp1 + (cd.z - ar2) * dp2;
+                    r6 = dchannel_dcolor * dp0; r7 = dchannel_dcolor * dp1; r8 = dchannel_dcolor * dp2;
+                    adr = last_alpha * ldp + (1.f - last_alpha) * adr; ldp = cd.w;
+                    dL_dalpha += (cd.w - adr) * ddep;
+                    r9 = dchannel_dcolor * ddep;
+                    aar = last_alpha + (1.f - last_alpha) * aar;
+                    dL_dalpha += (1.f - aar) * dalp;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = c.w * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * c.x - gdy * c.y;
+                    const float dG_ddely = -gdy * c.z - gdx * c.y;
+                    r0 = dL_dG * dG_ddelx * ddelx_dx;
+                    r1 = dL_dG * dG_ddely * ddely_dy;
+                    r2 = -0.5f * gdx * dx * dL_dG;
+                    r3 = -gdx * dy * dL_dG;
+                    r4 = -0.5f * gdy * dy * dL_dG;
+                    r5 = G * dL_dalpha;
+                }
+                r0 = wave_sum_to_lane63(r0); r1 = wave_sum_to_lane63(r1); r2 = wave_sum_to_lane63(r2);
+                r3 = wave_sum_to_lane63(r3); r4 = wave_sum_to_lane63(r4); r5 = wave_sum_to_lane63(r5);
+                r6 = wave_sum_to_lane63(r6); r7 = wave_sum_to_lane63(r7); r8 = wave_sum_to_lane63(r8);
+                r9 = wave_sum_to_lane63(r9);
+                if (lane == 63) {
+                    s_acc[wave][j][0] = make_float4(r0, r1, r2, r3);
+                    s_acc[wave][j][1] = make_float4(r4, r5, r6, r7);
+                    s_acc[wave][j][2] = make_float4(r8, r9, 0.f, 0.f);
+                }
+                if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
+            }
+        }
+        if (lane == 0) { s_mask[wave][0] = m0; s_mask[wave][1] = m1; }
+        __syncthreads();
+        // ---- write one record per pair (zeros when no wave touched it); fixed wave order => deterministic ----
+        if (tid < cnt) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned long long m = s_mask[w][tid >> 6];
+                if ((m >> (tid & 63)) & 1ull) {
+                    const float4 b0 = s_acc[w][tid][0], b1 = s_acc[w][tid][1], b2 = s_acc[w][tid][2];
+                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y;
+                }
+            }
+            const uint32_t pr = s_pair[tid];
+            if (pr < kp.cap) {
+                grad_pair[(size_t)pr * 3] = a0;
+                grad_pair[(size_t)pr * 3 + 1] = a1;
+                grad_pair[(size_t)pr * 3 + 2] = a2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.5 per-Gaussian backward: gather pair records, then the chain rule down to the inputs
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
+{
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= kp.P) return;
+    const size_t vg = (size_t)v * kp.P + g;
+    const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+    const float *view = vr, *proj = vr + 16;
+    const int radius = kp.radii[vg];
+
+    float gm[3] = { 0.f, 0.f, 0.f }, g2x = 0.f, g2y = 0.f, gop = 0.f;
+    float grgb[3] = { 0.f, 0.f, 0.f }, gsc[3] = { 0.f, 0.f, 0.f }, gq[4] = { 0.f, 0.f, 0.f, 0.f };
+    float gcov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    const int K = kp.shs ? (kp.deg + 1) * (kp.deg + 1) : 0;
+
+    if (radius > 0) {
+        // ---- gather the partial gradients of this Gaussian's tiles ----
+        const float2 p2 = kp.xy[vg];
+        int x0, y0, x1, y1;
+        tile_rect(p2.x, p2.y, radius, kp.gx, kp.gy, x0, y0, x1, y1);
+        const uint32_t npairs = (uint32_t)((x1 - x0) * (y1 - y0));
+        const uint32_t base = kp.pair_off[vg];
+        const float4 *gp = reinterpret_cast<const float4 *>(kp.grad_pair) + (size_t)v * kp.cap * 3;
+        float X = 0.f, Y = 0.f, Z = 0.f, gdep = 0.f;
+        for (uint32_t k = 0; k < npairs; k++) {
+            const uint32_t pr = base + k;
+            if (pr >= kp.cap) break;
+            const float4 a0 = gp[(size_t)pr * 3], a1 = gp[(size_t)pr * 3 + 1], a2 = gp[(size_t)pr * 3 + 2];
+            g2x += a0.x; g2y += a0.y; X += a0.z; Y += a0.w;
+            Z += a1.x; gop += a1.y; grgb[0] += a1.z; grgb[1] += a1.w;
+            grgb[2] += a2.x; gdep += a2.y;
+        }
+
+        const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+        float cov3[6];
+        float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+        float sc[3] = { 0.f, 0.f, 0.f };
+        if (kp.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov3[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+        } else {
+            sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
+            q = reinterpret_cast<const float4 *>(kp.rotations)[g];
+            cov3d_from_scale_rot(sc, kp.scale_modifier, q, cov3);
+        }
+        const float tanx = vr[38], tany = vr[39];
+        const float fx = kp.W / (2.0f * tanx), fy = kp.H / (2.0f * tany);
+        float T0[3], T1[3], t[3];
+        bool inx, iny;
+        ewa_rows(mean, view, fx, fy, tanx, tany, T0, T1, t, inx, iny);
+        float v0[3], v1[3];
+        sym3_mul(cov3, T0, v0);
+        sym3_mul(cov3, T1, v1);
+        const float a = T0[0] * v0[0] + T0[1] * v0[1] + T0[2] * v0[2] + T4D_COV2D_DILATION;
+        const float b = T0[0] * v1[0] + T0[1] * v1[1] + T0[2] * v1[2];
+        const float c = T1[0] * v1[0] + T1[1] * v1[1] + T1[2] * v1[2] + T4D_COV2D_DILATION;
+        const float denom = a * c - b * b;
+        const float d2inv = 1.f / ((denom * denom) + T4D_CONIC_BWD_EPS);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (d2inv != 0.f) {
+            dL_da = d2inv * (-c * c * X + b * c * Y + (denom - a * c) * Z);
+            dL_dc = d2inv * (-a * a * Z + a * b * Y + (denom - a * c) * X);
+            dL_db = d2inv * (2.f * b * c * X - (denom + 2.f * b * b) * Y + 2.f * a * b * Z);
+            gcov[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
+            gcov[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
+            gcov[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
+            gcov[1] = 2.f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.f * T1[0] * T1[1] * dL_dc;
+            gcov[2] = 2.f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.f * T1[0] * T1[2] * dL_dc;
+            gcov[4] = 2.f * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.f * T1[1] * T1[2] * dL_dc;
+        }
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float dT0 = 2.f * v0[j] * dL_da + v1[j] * dL_db;
+            const float dT1 = 2.f * v1[j] * dL_dc + v0[j] * dL_db;
+            dJ00 += view[j * 4 + 0] * dT0; dJ02 += view[j * 4 + 2] * dT0;
+            dJ11 += view[j * 4 + 1] * dT1; dJ12 += view[j * 4 + 2] * dT1;
+        }
+        const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = (inx ? 1.f : 0.f) * -fx * tz2 * dJ02;
+        const float dty = (iny ? 1.f : 0.f) * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t[0]) * tz3 * dJ02 + (2.f * fy * t[1]) * tz3 * dJ12;
+        gm[0] = view[0] * dtx + view[1] * dty + view[2] * dtz;
+        gm[1] = view[4] * dtx + view[5] * dty + view[6] * dtz;
+        gm[2] = view[8] * dtx + view[9] * dty + view[10] * dtz;
+
+        // screen position -> mean (perspective divide)
+        const float hx = proj[0] * mean[0] + proj[4] * mean[1] + proj[8] * mean[2] + proj[12];
+        const float hy = proj[1] * mean[0] + proj[5] * mean[1] + proj[9] * mean[2] + proj[13];
+        const float hw = proj[3] * mean[0] + proj[7] * mean[1] + proj[11] * mean[2] + proj[15];
+        const float mw = 1.0f / (hw + T4D_HOM_W_EPS);
+        const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+        gm[0] += (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
+        gm[1] += (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
+        gm[2] += (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
+        // view depth -> mean
+        gm[0] += view[2] * gdep; gm[1] += view[6] * gdep; gm[2] += view[10] * gdep;
+
+        // colour
+        if (kp.shs) {
+            const float d0[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
+            const float len = sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+            const float d[3] = { d0[0] / len, d0[1] / len, d0[2] / len };
+            float bas[16], bx[16], by[16], bz[16];
+            sh_basis(kp.deg, d, bas);
+            sh_basis_grad(kp.deg, d, bx, by, bz);
+            const uint32_t cl = kp.clamped[vg];
+            const float *sh = kp.shs + (size_t)g * kp.M * 3;
+            float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
+            float gd[3] = { 0.f, 0.f, 0.f };
+            const float gc[3] = { (cl & 1u) ? 0.f : grgb[0], (cl & 2u) ? 0.f : grgb[1], (cl & 4u) ? 0.f : grgb[2] };
+            for (int k = 0; k < kp.M; k++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float o = 0.f;
+                    if (k < K) {
+                        const float s = sh[k * 3 + ch];
+                        o = bas[k] * gc[ch];
+                        gd[0] += bx[k] * s * gc[ch]; gd[1] += by[k] * s * gc[ch]; gd[2] += bz[k] * s * gc[ch];
+                    }
+                    gsh[k * 3 + ch] = o;
+                }
+            }
+            const float dot = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) gm[j] += (gd[j] - d[j] * dot) / len;
+        }
+
+        // cov3D -> scale, rotation
+        if (!kp.cov3D_precomp) {
+            float R[9];
+            quat_rot(q, R);
+            const float s[3] = { kp.scale_modifier * sc[0], kp.scale_modifier * sc[1], kp.scale_modifier * sc[2] };
+            const float Gs[9] = { gcov[0], 0.5f * gcov[1], 0.5f * gcov[2], 0.5f * gcov[1], gcov[3], 0.5f * gcov[4],
+                                  0.5f * gcov[2], 0.5f * gcov[4], gcov[5] };
+            float Mp[9], D[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) Mp[r * 3 + k] = R[r * 3 + k] * s[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float dM[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    dM[r] = 2.f * (Gs[r * 3] * Mp[k] + Gs[r * 3 + 1] * Mp[3 + k] + Gs[r * 3 + 2] * Mp[6 + k]);
+                gsc[k] = kp.scale_modifier * (dM[0] * R[k] + dM[1] * R[3 + k] + dM[2] * R[6 + k]);
+#pragma unroll
+                for (int r = 0; r < 3; r++) D[r * 3 + k] = dM[r] * s[k];
+            }
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            gq[0] = 2.f * z * (D[3] - D[1]) + 2.f * y * (D[2] - D[6]) + 2.f * x * (D[7] - D[5]);
+            gq[1] = 2.f * y * (D[1] + D[3]) + 2.f * z * (D[2] + D[6]) + 2.f * r * (D[7] - D[5]) - 4.f * x * (D[4] + D[8]);
+            gq[2] = 2.f * x * (D[1] + D[3]) + 2.f * r * (D[2] - D[6]) + 2.f * z * (D[5] + D[7]) - 4.f * y * (D[0] + D[8]);
+            gq[3] = 2.f * r * (D[3] - D[1]) + 2.f * x * (D[2] + D[6]) + 2.f * y * (D[5] + D[7]) - 4.f * z * (D[0] + D[4]);
+        }
+    } else if (kp.shs) {
+        float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
+        for (int k = 0; k < kp.M * 3; k++) gsh[k] = 0.f;
+    }
+
+    kp.dL_dmeans3D[vg * 3] = gm[0]; kp.dL_dmeans3D[vg * 3 + 1] = gm[1]; kp.dL_dmeans3D[vg * 3 + 2] = gm[2];
+    kp.dL_dmeans2D[vg * 3] = g2x; kp.dL_dmeans2D[vg * 3 + 1] = g2y; kp.dL_dmeans2D[vg * 3 + 2] = 0.f;
+    kp.dL_dopacities[vg] = gop;
+    if (kp.dL_dcolors) { kp.dL_dcolors[vg * 3] = grgb[0]; kp.dL_dcolors[vg * 3 + 1] = grgb[1]; kp.dL_dcolors[vg * 3 + 2] = grgb[2]; }
+    if (kp.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) kp.dL_dcov3D[vg * 6 + k] = gcov[k];
+    } else {
+        kp.dL_dscales[vg * 3] = gsc[0]; kp.dL_dscales[vg * 3 + 1] = gsc[1]; kp.dL_dscales[vg * 3 + 2] = gsc[2];
+        reinterpret_cast<float4 *>(kp.dL_drotations)[vg] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mark_visible(int P, const float *means3D, const float *view, uint8_t *present)
+{
+#pragma clang fp contract(off)
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= P) return;
+    const float z = view[2] * means3D[3 * (size_t)g] + view[6] * means3D[3 * (size_t)g + 1] +
+                    view[10] * means3D[3 * (size_t)g + 2] + view[14];
+    present[g] = z > T4D_NEAR_CULL_Z ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+int fail(int code, const char *fmt, const char *a = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+
+#define T4D_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return fail(T4D_ERR_HIP, #call ": %s", hipGetErrorString(e_));  \
+    } while (0)
+
+struct ProfScope {
+    hipStream_t s; int id; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(hipStream_t s_, int id_) : s(s_), id(id_), on(g_prof_on)
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope()
+    {
+        if (on) { (void)hipEventRecord(b, s); g_prof.push_back({ id, a, b }); }
+    }
+};
+
+#define T4D_LAUNCH_CHECK(name)                                                                 \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) return fail(T4D_ERR_HIP, name " launch: %s", hipGetErrorString(e_)); \
+        if (debug) {                                                                           \
+            e_ = hipStreamSynchronize(stream);                                                 \
+            if (e_ != hipSuccess) return fail(T4D_ERR_HIP, name " exec: %s", hipGetErrorString(e_)); \
+        }                                                                                      \
+    } while (0)
+
+int check_problem(const T4DProblem *p)
+{
+    if (!p) return fail(T4D_ERR_ARG, "null problem");
+    if (p->abi_version != T4D_ABI_VERSION) return fail(T4D_ERR_ARG, "abi_version mismatch");
+    if (p->n_views < 1 || p->P < 1 || p->H < 1 || p->W < 1) return fail(T4D_ERR_ARG, "n_views, P, H, W must be >= 1");
+    if (p->n_views > 65535) return fail(T4D_ERR_ARG, "n_views must be <= 65535");
+    if (p->pair_capacity < 1 || p->pair_capacity > 0x7fffffffLL) return fail(T4D_ERR_ARG, "pair_capacity out of range");
+    if (p->sh_coeffs < 0 || p->sh_degree < 0 || p->sh_degree > 3) return fail(T4D_ERR_ARG, "sh_degree must be 0..3");
+    if (p->sh_coeffs > 0 && p->sh_coeffs < (p->sh_degree + 1) * (p->sh_degree + 1))
+        return fail(T4D_ERR_ARG, "sh_coeffs smaller than (sh_degree+1)^2");
+    return T4D_OK;
+}
+
+void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
+{
+    kp.V = p.n_views; kp.P = p.P; kp.H = p.H; kp.W = p.W;
+    kp.gx = (p.W + T4D_TILE_X - 1) / T4D_TILE_X;
+    kp.gy = (p.H + T4D_TILE_Y - 1) / T4D_TILE_Y;
+    kp.T = kp.gx * kp.gy;
+    kp.deg = p.sh_degree; kp.M = p.sh_coeffs;
+    kp.scale_modifier = p.scale_modifier;
+    kp.cap = (uint32_t)p.pair_capacity;
+    kp.status = reinterpret_cast<DevStatus *>(st + L.status);
+    kp.view_total = reinterpret_cast<uint32_t *>(st + L.view_total);
+    kp.view_cursor = reinterpret_cast<uint32_t *>(st + L.view_cursor);
+    kp.tile_count = reinterpret_cast<uint32_t *>(st + L.tile_count);
+    kp.tile_cursor = reinterpret_cast<uint32_t *>(st + L.tile_cursor);
+    kp.tile_off = reinterpret_cast<uint32_t *>(st + L.tile_off);
+    kp.pair_off = reinterpret_cast<uint32_t *>(st + L.pair_off);
+    kp.xy = reinterpret_cast<float2 *>(st + L.xy);
+    kp.depth = reinterpret_cast<float *>(st + L.depth);
+    kp.conic_opacity = reinterpret_cast<float4 *>(st + L.conic_opacity);
+    kp.rgb = reinterpret_cast<float *>(st + L.rgb);
+    kp.clamped = reinterpret_cast<uint8_t *>(st + L.clamped);
+    kp.keys = reinterpret_cast<unsigned long long *>(st + L.keys);
+    kp.final_T = reinterpret_cast<float *>(st + L.final_T);
+    kp.n_contrib = reinterpret_cast<uint32_t *>(st + L.n_contrib);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+T4D_EXPORT uint32_t t4d_abi_version(void) { return T4D_ABI_VERSION; }
+T4D_EXPORT const char *t4d_last_error(void) { return g_err; }
+
+T4D_EXPORT size_t t4d_state_bytes(const T4DProblem *prob)
+{
+    if (check_problem(prob) != T4D_OK) return 0;
+    return make_layout(*prob).total;
+}
+
+T4D_EXPORT size_t t4d_backward_scratch_bytes(const T4DProblem *prob)
+{
+    if (check_problem(prob) != T4D_OK) return 0;
+    return align_up((size_t)prob->n_views * (size_t)prob->pair_capacity * kGP * sizeof(float));
+}
+
+T4D_EXPORT int t4d_debug_state_layout(const T4DProblem *prob, int has_sh, uint64_t *offsets, int n)
+{
+    int rc = check_problem(prob);
+    if (rc != T4D_OK) return rc;
+    if (!offsets || n < T4D_DEBUG_LAYOUT_FIELDS) return fail(T4D_ERR_ARG, "offsets must hold T4D_DEBUG_LAYOUT_FIELDS entries");
+    T4DProblem p = *prob;
+    if (!has_sh) p.sh_coeffs = 0;
+    const Layout L = make_layout(p);
+    const size_t f[T4D_DEBUG_LAYOUT_FIELDS] = { L.status, L.view_total, L.view_cursor, L.tile_count, L.tile_cursor, L.tile_off,
+                                                L.xy, L.depth, L.conic_opacity, L.rgb, L.clamped, L.pair_off, L.keys,
+                                                L.final_T, L.n_contrib, L.total };
+    for (int i = 0; i < T4D_DEBUG_LAYOUT_FIELDS; i++) offsets[i] = (uint64_t)f[i];
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO *io, T4DStatus *status, void *hip_stream)
+{
+    int rc = check_problem(prob);
+    if (rc != T4D_OK) return rc;
+    if (!io || !io->views || !io->means3D || !io->opacities || !io->out_color || !io->out_depth || !io->out_alpha ||
+        !io->out_radii || !io->state)
+        return fail(T4D_ERR_ARG, "null required pointer in T4DForwardIO");
+    if ((io->shs == nullptr) == (io->colors_precomp == nullptr))
+        return fail(T4D_ERR_ARG, "provide exactly one of shs / colors_precomp");
+    if (io->cov3D_precomp ? (io->scales || io->rotations) : (!io->scales || !io->rotations))
+        return fail(T4D_ERR_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (io->shs && prob->sh_coeffs < 1) return fail(T4D_ERR_ARG, "shs given but sh_coeffs == 0");
+    T4DProblem p = *prob;
+    if (!io->shs) p.sh_coeffs = 0;
+    const Layout L = make_layout(p);
+    if (io->state_bytes < L.total) return fail(T4D_ERR_STATE_SIZE, "state buffer smaller than t4d_state_bytes()");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool debug = (p.flags & T4D_FLAG_DEBUG_SYNC) != 0;
+    const bool checked = debug || (p.flags & T4D_FLAG_CHECKED) != 0;
+    char *st = (char *)io->state;
+
+    KP kp;
+    memset(&kp, 0, sizeof(kp));
+    fill_common(kp, p, L, st);
+    kp.views = io->views; kp.means3D = io->means3D; kp.opacities = io->opacities; kp.scales = io->scales;
+    kp.rotations = io->rotations; kp.cov3D_precomp = io->cov3D_precomp; kp.colors_precomp = io->colors_precomp;
+    kp.shs = io->shs;
+    kp.out_color = io->out_color; kp.out_depth = io->out_depth; kp.out_alpha = io->out_alpha; kp.radii = io->out_radii;
+
+    T4D_HIP(hipMemsetAsync(st, 0, L.zero_end, stream));
+    const dim3 gP((p.P + kBlock - 1) / kBlock, p.n_views);
+    { ProfScope ps_(stream, K_PREPROCESS);
+    hipLaunchKernelGGL(k_preprocess, gP, dim3(kBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_preprocess");
+    { ProfScope ps_(stream, K_SCAN_TILES);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(p.n_views), dim3(1024), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_scan_tiles");
+    if (checked) {
+        DevStatus hs;
+        T4D_HIP(hipMemcpyAsync(&hs, st + L.status, sizeof(hs), hipMemcpyDeviceToHost, stream));
+        T4D_HIP(hipStreamSynchronize(stream));
+        if (status) {
+            status->max_pairs_per_view = hs.max_pairs;
+            status->total_pairs = (int64_t)hs.total_pairs;
+            status->overflow = (int32_t)hs.overflow;
+            status->reserved = 0;
+        }
+        if (hs.overflow) return fail(T4D_ERR_PAIR_OVERFLOW, "pair_capacity too small for this scene");
+    }
+    { ProfScope ps_(stream, K_SCATTER);
+    hipLaunchKernelGGL(k_scatter, gP, dim3(kBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_scatter");
+    { ProfScope ps_(stream, K_SORT_TILES);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(kp.T, p.n_views), dim3(kBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_sort_tiles");
+    { ProfScope ps_(stream, K_RENDER_FWD);
+    hipLaunchKernelGGL(k_render_fwd, dim3(kp.gx, kp.gy, p.n_views), dim3(kBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_render_fwd");
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardIO *io, void *hip_stream)
+{
+    int rc = check_problem(prob);
+    if (rc != T4D_OK) return rc;
+    if (!io || !io->views || !io->means3D || !io->opacities || !io->radii || !io->state || !io->dL_dcolor ||
+        !io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacities || !io->scratch)
+        return fail(T4D_ERR_ARG, "null required pointer in T4DBackwardIO");
+    if ((io->shs == nullptr) == (io->colors_precomp == nullptr))
+        return fail(T4D_ERR_ARG, "provide exactly one of shs / colors_precomp");
+    if (io->cov3D_precomp ? (io->scales || io->rotations) : (!io->scales || !io->rotations))
+        return fail(T4D_ERR_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (io->shs ? !io->dL_dshs : !io->dL_dcolors) return fail(T4D_ERR_ARG, "missing colour gradient output");
+    if (io->cov3D_precomp ? !io->dL_dcov3D : (!io->dL_dscales || !io->dL_drotations))
+        return fail(T4D_ERR_ARG, "missing covariance gradient output");
+    T4DProblem p = *prob;
+    if (!io->shs) p.sh_coeffs = 0;
+    const Layout L = make_layout(p);
+    if (io->state_bytes < L.total) return fail(T4D_ERR_STATE_SIZE, "state buffer smaller than t4d_state_bytes()");
+    if (io->scratch_bytes < t4d_backward_scratch_bytes(&p))
+        return fail(T4D_ERR_STATE_SIZE, "scratch smaller than t4d_backward_scratch_bytes()");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool debug = (p.flags & T4D_FLAG_DEBUG_SYNC) != 0;
+    char *st = (char *)io->state;
+
+    KP kp;
+    memset(&kp, 0, sizeof(kp));
+    fill_common(kp, p, L, st);
+    kp.views = io->views; kp.means3D = io->means3D; kp.opacities = io->opacities; kp.scales = io->scales;
+    kp.rotations = io->rotations; kp.cov3D_precomp = io->cov3D_precomp; kp.colors_precomp = io->colors_precomp;
+    kp.shs = io->shs;
+    kp.radii = const_cast<int32_t *>(io->radii);
+    kp.dL_dcolor = io->dL_dcolor; kp.dL_ddepth = io->dL_ddepth; kp.dL_dalpha = io->dL_dalpha;
+    kp.grad_pair = (float *)io->scratch;
+    kp.dL_dmeans3D = io->dL_dmeans3D; kp.dL_dmeans2D = io->dL_dmeans2D; kp.dL_dcolors = io->dL_dcolors;
+    kp.dL_dshs = io->dL_dshs; kp.dL_dopacities = io->dL_dopacities; kp.dL_dscales = io->dL_dscales;
+    kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
+
+    { ProfScope ps_(stream, K_RENDER_BWD);
+    hipLaunchKernelGGL(k_render_bwd, dim3(kp.gx, kp.gy, p.n_views), dim3(kBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_render_bwd");
+    { ProfScope ps_(stream, K_PREPROCESS_BWD);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + kBlock - 1) / kBlock, p.n_views), dim3(kBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_preprocess_bwd");
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_profile_begin(void)
+{
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_profile_end(T4DKernelTime *out, int max_entries, int *n_entries)
+{
+    g_prof_on = false;
+    if (!out || !n_entries || max_entries < K_COUNT) return fail(T4D_ERR_ARG, "need room for every kernel");
+    for (int k = 0; k < K_COUNT; k++) {
+        out[k].name = kKernelNames[k];
+        out[k].total_ms = 0.0;
+        out[k].launches = 0;
+    }
+    for (auto &r : g_prof) {
+        T4D_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        T4D_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        out[r.id].total_ms += ms;
+        out[r.id].launches += 1;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    *n_entries = K_COUNT;
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_fetch_status(const T4DProblem *prob, const void *state, T4DStatus *out, void *hip_stream)
+{
+    int rc = check_problem(prob);
+    if (rc != T4D_OK) return rc;
+    if (!state || !out) return fail(T4D_ERR_ARG, "null pointer");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DevStatus hs;
+    T4D_HIP(hipMemcpyAsync(&hs, state, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    T4D_HIP(hipStreamSynchronize(stream));
+    out->max_pairs_per_view = hs.max_pairs;
+    out->total_pairs = (int64_t)hs.total_pairs;
+    out->overflow = (int32_t)hs.overflow;
+    out->reserved = 0;
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_mark_visible(int32_t P, const float *means3D, const float *view, uint8_t *present, void *hip_stream)
+{
+    if (P < 0 || (P > 0 && (!means3D || !view || !present))) return fail(T4D_ERR_ARG, "bad arguments");
+    if (P == 0) return T4D_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool debug = false;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, P, means3D, view, present);
+    T4D_LAUNCH_CHECK("k_mark_visible");
+    return T4D_OK;
+}

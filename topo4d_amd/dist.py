@@ -1,0 +1,64 @@
+"""
+Multi-GPU driver for the render hot path: one process per GPU (torchrun), units sharded, losses gathered.
+
+The reference is single-process / single-GPU; this is the one parallel axis the hot path has:
+every (frame, view) render reads the same replicated Gaussians and its own camera, so units are independent
+(SURVEY.md §8e).  Rank r of W takes units {u : u mod W == r}.  No data-path collective exists; the only exchange
+is an all_gather of the per-view scalar photometric losses (a few floats per rank) — RCCL on GPU ("nccl" backend
+is RCCL on ROCm), gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+
+def shard_units(n_units: int, rank: int, world: int) -> List[int]:
+    """Round-robin shard: units rank, rank+world, ... (24 views over 8 ranks -> 3 views each)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return list(range(rank, n_units, world))
+
+
+def shard_sizes(n_units: int, world: int) -> List[int]:
+    return [len(range(r, n_units, world)) for r in range(world)]
+
+
+def gather_losses(local: torch.Tensor, n_units: int = None) -> torch.Tensor:
+    """all_gather of per-unit scalar losses.  `local` is this rank's 1-D tensor (round-robin shard of n_units
+    units; ranks may hold different counts).  Returns the losses of ALL units in unit order, on every rank."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if n_units is None:                       # equal shards
+        out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        # rank-major -> unit order (unit u lives on rank u % world at position u // world)
+        return out.view(world, -1).t().reshape(-1)
+    sizes = shard_sizes(n_units, world)
+    m = max(sizes)
+    padded = torch.zeros(m, dtype=local.dtype, device=local.device)
+    padded[: local.numel()] = local
+    out = torch.empty(world * m, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded)
+    out = out.view(world, m)
+    res = torch.empty(n_units, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        res[r::world] = out[r, : sizes[r]]
+    return res
+
+
+def all_reduce_grads(grads: Sequence[torch.Tensor]) -> None:
+    """Optional data-parallel training step: sum the (already view-summed) parameter gradients over ranks.
+    Changes the optimisation schedule versus train.py:661-673 (one Adam step per view) — see DESIGN.md."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    o = 0
+    for g in grads:
+        g.copy_(flat[o: o + g.numel()].view_as(g))
+        o += g.numel()
