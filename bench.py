@@ -140,7 +140,7 @@ def main():
         color, radii, depth, alpha = batch.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
                                                    rv.get("colors_precomp"), rv.get("shs"))
         g = batch.backward(dc)
-        torch.mul(color, dc).sum(dim=(1, 2, 3), out=losses)     # per-view scalar "photometric" loss
+        torch.sum(color * dc, dim=(1, 2, 3), out=losses)     # per-view scalar "photometric" loss
         if world > 1:
             return t4d_dist.gather_losses(losses), g
         return losses, g

@@ -522,8 +522,15 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// A.3 forward blend.  Workgroup = 16x16 tile; wave w owns the 8x8 block (w&1, w>>1), lane l pixel (l&7, l>>3).
+// A.3 / A.4 shared pieces.
+// Workgroup = 16x16 tile; wave w owns the 8x8 pixel block (w&1, w>>1); lane l the pixel (l&7, l>>3).
+// Per staged splat one lane computes, for each of the 4 blocks, a CONSERVATIVE test "can alpha reach 1/255 on any
+// pixel centre of the block?"; the four wave64 ballots become per-block bit masks and every wave only visits
+// the set bits of its own mask (s_ff1 / s_flbit on an SGPR pair).  Skipped splats would have been rejected by
+// the per-pixel alpha < 1/255 test anyway, so results are unchanged.
 // ---------------------------------------------------------------------------------------------------------
+constexpr float kLog2e = 1.4426950408889634f;
+
 __device__ __forceinline__ void tile_pixel(int tid, int tx, int ty, int &px, int &py)
 {
     const int w = tid >> 6, l = tid & 63;
@@ -531,12 +538,64 @@ __device__ __forceinline__ void tile_pixel(int tid, int tx, int ty, int &px, int
     py = ty * T4D_TILE_Y + ((w >> 1) << 3) + (l >> 3);
 }
 
+// squared cut-off radius (pixels) beyond which opacity * exp(power) < 1/255 with margin; +inf = "cannot cull"
+__device__ __forceinline__ float cutoff_radius2(const float4 co)
+{
+    const float lnarg = __logf(255.0f * co.w);               // alpha_max = opacity  =>  ln(255*opacity)
+    if (!(lnarg > -1e-3f)) return -1.0f;                     // opacity < 1/255 (with margin): never contributes
+    const float mid = 0.5f * (co.x + co.z);
+    const float det = co.x * co.z - co.y * co.y;
+    const float disc = mid * mid - det;
+    const float lmin = det / (mid + sqrtf(fmaxf(disc, 0.f)));  // smallest eigenvalue of the conic, stable form
+    if (!(lmin > 0.f) || !(mid > 0.f)) return __builtin_huge_valf();   // not positive definite / NaN: no culling
+    return 2.0f * (lnarg + 2e-3f) / lmin * 1.001f;
+}
+
+// bit w set <=> the splat centred at p with cut-off r2 can touch 8x8 block w of tile (tx,ty)
+__device__ __forceinline__ uint32_t block_touch_mask(const float2 p, const float r2, const int tx, const int ty)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float bx0 = (float)(tx * T4D_TILE_X + ((w & 1) << 3)), by0 = (float)(ty * T4D_TILE_Y + ((w >> 1) << 3));
+        const float ddx = fmaxf(fmaxf(bx0 - p.x, p.x - (bx0 + 7.f)), 0.f);
+        const float ddy = fmaxf(fmaxf(by0 - p.y, p.y - (by0 + 7.f)), 0.f);
+        if (!(ddx * ddx + ddy * ddy > r2)) m |= 1u << w;
+    }
+    return m;
+}
+
+// The ONE place alpha is evaluated, shared by forward and backward so that both take bit-identical decisions.
+// q = (A, B, C) * log2(e) pre-multiplied by (-0.5, -1, -0.5); returns p2 = power * log2(e), G = exp(power).
+__device__ __forceinline__ void eval_splat(const float4 q, const float dx, const float dy, float &p2, float &G, float &alpha)
+{
+#pragma clang fp contract(off)
+    p2 = fmaf(q.x * dx, dx, fmaf(q.z * dy, dy, (q.y * dx) * dy));
+    G = __builtin_amdgcn_exp2f(p2);
+    alpha = fminf(T4D_ALPHA_MAX, q.w * G);
+}
+
+__device__ __forceinline__ float4 scale_conic(const float4 co)
+{
+#pragma clang fp contract(off)
+    return make_float4(co.x * (-0.5f * kLog2e), co.y * (-kLog2e), co.z * (-0.5f * kLog2e), co.w);
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
 {
     __shared__ float2 s_xy[kFwdBatch];
-    __shared__ float4 s_co[kFwdBatch];
+    __shared__ float4 s_q[kFwdBatch];    // scaled conic + opacity
     __shared__ float4 s_cd[kFwdBatch];   // rgb + depth
+    __shared__ unsigned long long s_mask[4][kFwdBatch / 64];
     const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const size_t vt = (size_t)v * kp.T + (size_t)ty * kp.gx + tx;
     const uint32_t off = kp.tile_off[vt];
     uint32_t n = kp.tile_count[vt];
@@ -552,38 +611,55 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
     const float pxf = (float)px, pyf = (float)py;
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, D = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
 
     for (uint32_t b = 0; b < n; b += kFwdBatch) {
         if (__syncthreads_count(done) == kBlock) break;
+        uint32_t touch = 0;
         if (b + tid < n) {
             const unsigned long long key = keys[b + tid];
             const uint32_t g = (uint32_t)key;
-            s_xy[tid] = xy[g];
-            s_co[tid] = co[g];
+            const float2 p = xy[g];
+            const float4 c = co[g];
+            s_xy[tid] = p;
+            s_q[tid] = scale_conic(c);
             s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
                                     __uint_as_float((uint32_t)(key >> 32)));
+            touch = block_touch_mask(p, cutoff_radius2(c), tx, ty);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned long long bal = __ballot((touch >> w) & 1u);
+            if (lane == 0) s_mask[w][wave] = bal;
         }
         __syncthreads();
-        const int cnt = (int)min((uint32_t)kFwdBatch, n - b);
-        for (int j = 0; !done && j < cnt; j++) {
-            contributor++;
-            const float2 g_xy = s_xy[j];
-            const float dx = g_xy.x - pxf, dy = g_xy.y - pyf;
-            const float4 c = s_co[j];
-            const float power = -0.5f * (c.x * dx * dx + c.z * dy * dy) - c.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(T4D_ALPHA_MAX, c.w * expf(power));
-            if (alpha < T4D_ALPHA_MIN) continue;
-            const float test_T = T * (1.f - alpha);
-            if (test_T < T4D_T_STOP) { done = true; continue; }
-            const float4 cd = s_cd[j];
-            const float w = alpha * T;
-            C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-            Wt += w;
-            D += cd.w * w;
-            T = test_T;
-            last_contributor = contributor;
+        if (!__all(done)) {
+            for (int c4 = 0; c4 < kFwdBatch / 64; c4++) {
+                unsigned long long m = uniform_u64(s_mask[wave][c4]);
+                while (m) {
+                    const int j = (c4 << 6) + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float2 g_xy = s_xy[j];
+                    const float4 q = s_q[j];
+                    float p2, G, alpha;
+                    eval_splat(q, g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha);
+                    bool ok = !done && !(p2 > 0.0f) && !(alpha < T4D_ALPHA_MIN);
+                    const float test_T = T * (1.f - alpha);
+                    const bool stop = ok && test_T < T4D_T_STOP;
+                    done = done || stop;
+                    ok = ok && !stop;
+                    if (__any(ok)) {
+                        const float4 cd = s_cd[j];
+                        const float w = ok ? alpha * T : 0.f;
+                        C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
+                        D = fmaf(cd.w, w, D);
+                        Wt += w;
+                        T = ok ? test_T : T;
+                        last_contributor = ok ? b + (uint32_t)j + 1u : last_contributor;
+                    }
+                    if (__all(done)) { m = 0; c4 = kFwdBatch; }
+                }
+            }
         }
     }
     if (inside) {
@@ -601,17 +677,76 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// wave64 reduction of TEN values at once ("transpose-reduce"): at every butterfly level two partial-sum vectors
+// are folded into one, each half of the lanes keeping a different value, so the work halves per level instead of
+// staying at 10 adds x 6 levels.  Levels: xor32 / xor16 by v_permlane{32,16}_swap (gfx950), xor8 by row_ror:8,
+// xor4 by two bank-masked row shifts, xor2 / xor1 by quad_perm.  27 VALU instead of 60.
+// On return lane L (L % 4 == 0) holds the wave-wide sum of value red10_index(L) (or garbage when that is < 0).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float swap32_add(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dppz(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, true));
+}
+
+__device__ __forceinline__ float reduce10(const float r[10], const int lane)
+{
+    // level xor32: lanes <32 keep the even member of each pair, lanes >=32 the odd one
+    const float s0 = swap32_add(r[0], r[1]), s1 = swap32_add(r[2], r[3]), s2 = swap32_add(r[4], r[5]);
+    const float s3 = swap32_add(r[6], r[7]), s4 = swap32_add(r[8], r[9]);
+    // level xor16: even rows keep the first member, odd rows the second
+    const float t0 = swap16_add(s0, s1), t1 = swap16_add(s2, s3), t2 = swap16_add(s4, 0.f);
+    // level xor8 (row_ror:8)
+    const bool b3 = (lane & 8) != 0;
+    const float keep8 = b3 ? t1 : t0, send8 = b3 ? t0 : t1;
+    const float u0 = keep8 + dppz<0x128>(0.f, send8);
+    const float u1 = t2 + dppz<0x128>(0.f, t2);
+    // level xor4: banks {0,2} read lane+4 (row_shl:4), banks {1,3} read lane-4 (row_shr:4)
+    const bool b2 = (lane & 4) != 0;
+    const float keep4 = b2 ? u1 : u0, send4 = b2 ? u0 : u1;
+    float recv = dppz<0x104, 0x5>(0.f, send4);
+    recv = dppz<0x114, 0xA>(recv, send4);
+    float w = keep4 + recv;
+    // levels xor1, xor2 inside each quad
+    w += dppz<0xB1>(0.f, w);
+    w += dppz<0x4E>(0.f, w);
+    return w;
+}
+
+// which of the ten values lane L (L % 4 == 0) holds after reduce10; -1 = none
+__device__ __forceinline__ int red10_index(const int lane)
+{
+    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+    if (lane & 3) return -1;
+    if (b2) return (b3 || b4) ? -1 : 8 + b5;
+    return 4 * b3 + 2 * b4 + b5;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // A.4 backward replay.  No global atomics: one kGP-float record per (Gaussian,tile) pair.
 // record: [0,1] d/d(ndc xy)  [2,3,4] d/d(conic A,B,C)  [5] d/d opacity  [6,7,8] d/d rgb  [9] d/d depth
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
 {
     __shared__ float2 s_xy[kBwdBatch];
-    __shared__ float4 s_co[kBwdBatch];
+    __shared__ float4 s_co[kBwdBatch];   // raw conic + opacity
+    __shared__ float4 s_q[kBwdBatch];    // scaled conic + opacity (alpha evaluation)
     __shared__ float4 s_cd[kBwdBatch];
     __shared__ uint32_t s_pair[kBwdBatch];
-    __shared__ float4 s_acc[4][kBwdBatch][3];
-    __shared__ unsigned long long s_mask[4][kBwdBatch / 64];
+    __shared__ float s_acc[4][kBwdBatch][kGP];
+    __shared__ unsigned long long s_mask[4][kBwdBatch / 64];   // cull masks (in), then "slab written" masks (out)
     __shared__ uint32_t s_wmax[4];
 
     const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
@@ -651,6 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
     float adr = 0.f, ldp = 0.f, aar = 0.f, last_alpha = 0.f;
     const float bg_dot = vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2;
     const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
+    const int my_slot = red10_index(lane);
 
     const uint32_t wave_max = wave_max_u32(last_contributor);
     if (lane == 0) s_wmax[wave] = wave_max;
@@ -663,6 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
         const int cnt = (int)min((uint32_t)kBwdBatch, n - lo);
         const bool live = lo < tile_max;      // workgroup-uniform
         // ---- stage ----
+        uint32_t touch = 0;
         if (tid < cnt) {
             const unsigned long long key = keys[lo + tid];
             const uint32_t g = (uint32_t)key;
@@ -671,89 +808,108 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
             tile_rect(p.x, p.y, radii[g], kp.gx, kp.gy, x0, y0, x1, y1);
             s_pair[tid] = pair_off[g] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
             if (live) {
+                const float4 c = co[g];
                 s_xy[tid] = p;
-                s_co[tid] = co[g];
+                s_co[tid] = c;
+                s_q[tid] = scale_conic(c);
                 s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
                                         __uint_as_float((uint32_t)(key >> 32)));
+                touch = block_touch_mask(p, cutoff_radius2(c), tx, ty);
+            }
+        }
+        if (wave < kBwdBatch / 64) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned long long bal = __ballot((touch >> w) & 1u);
+                if (lane == 0) s_mask[w][wave] = bal;
             }
         }
         __syncthreads();
-        unsigned long long m0 = 0ull, m1 = 0ull;
+        unsigned long long wrote[kBwdBatch / 64];
+#pragma unroll
+        for (int c2 = 0; c2 < kBwdBatch / 64; c2++) wrote[c2] = 0ull;
         if (live) {
-            for (int j = cnt - 1; j >= 0; j--) {
-                const uint32_t pos = lo + (uint32_t)j;
-                if (pos >= wave_max) continue;                 // wave-uniform
-                bool contrib = pos < last_contributor;
-                const float2 g_xy = s_xy[j];
-                const float dx = g_xy.x - pxf, dy = g_xy.y - pyf;
-                const float4 c = s_co[j];
-                const float power = -0.5f * (c.x * dx * dx + c.z * dy * dy) - c.y * dx * dy;
-                const float G = expf(power);
-                const float alpha = fminf(T4D_ALPHA_MAX, c.w * G);
-                contrib = contrib && !(power > 0.0f) && !(alpha < T4D_ALPHA_MIN);
-                if (!__any(contrib)) continue;                 // wave-uniform
-                float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f, r8 = 0.f, r9 = 0.f;
-                if (contrib) {
-                    const float4 cd = s_cd[j];
-                    T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha;
-                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = cd.x;
-                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = cd.y;
-                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = cd.z;
-                    dL_dalpha = (cd.x - ar0) * dp0 + (cd.y - ar1) * dp1 + (cd.z - ar2) * dp2;
-                    r6 = dchannel_dcolor * dp0; r7 = dchannel_dcolor * dp1; r8 = dchannel_dcolor * dp2;
-                    adr = last_alpha * ldp + (1.f - last_alpha) * adr; ldp = cd.w;
-                    dL_dalpha += (cd.w - adr) * ddep;
-                    r9 = dchannel_dcolor * ddep;
-                    aar = last_alpha + (1.f - last_alpha) * aar;
-                    dL_dalpha += (1.f - aar) * dalp;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                    const float dL_dG = c.w * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * c.x - gdy * c.y;
-                    const float dG_ddely = -gdy * c.z - gdx * c.y;
-                    r0 = dL_dG * dG_ddelx * ddelx_dx;
-                    r1 = dL_dG * dG_ddely * ddely_dy;
-                    r2 = -0.5f * gdx * dx * dL_dG;
-                    r3 = -gdx * dy * dL_dG;
-                    r4 = -0.5f * gdy * dy * dL_dG;
-                    r5 = G * dL_dalpha;
+#pragma unroll
+            for (int c2 = kBwdBatch / 64 - 1; c2 >= 0; c2--) {
+                unsigned long long m = uniform_u64(s_mask[wave][c2]);
+                while (m) {
+                    const int jb = 63 - __builtin_clzll(m);
+                    m &= ~(1ull << jb);
+                    const int j = (c2 << 6) + jb;
+                    const uint32_t pos = lo + (uint32_t)j;
+                    if (pos >= wave_max) continue;                 // wave-uniform
+                    const float2 g_xy = s_xy[j];
+                    const float dx = g_xy.x - pxf, dy = g_xy.y - pyf;
+                    float p2, G, alpha;
+                    eval_splat(s_q[j], dx, dy, p2, G, alpha);
+                    const bool contrib = pos < last_contributor && !(p2 > 0.0f) && !(alpha < T4D_ALPHA_MIN);
+                    if (!__any(contrib)) continue;                 // wave-uniform
+                    float r[10];
+#pragma unroll
+                    for (int k = 0; k < 10; k++) r[k] = 0.f;
+                    if (contrib) {
+                        const float4 c = s_co[j];
+                        const float4 cd = s_cd[j];
+                        T = T / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * T;
+                        float dL_dalpha;
+                        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = cd.x;
+                        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = cd.y;
+                        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = cd.z;
+                        dL_dalpha = (cd.x - ar0) * dp0 + (cd.y - ar1) * dp1 + (cd.z - ar2) * dp2;
+                        r[6] = dchannel_dcolor * dp0; r[7] = dchannel_dcolor * dp1; r[8] = dchannel_dcolor * dp2;
+                        adr = last_alpha * ldp + (1.f - last_alpha) * adr; ldp = cd.w;
+                        dL_dalpha += (cd.w - adr) * ddep;
+                        r[9] = dchannel_dcolor * ddep;
+                        aar = last_alpha + (1.f - last_alpha) * aar;
+                        dL_dalpha += (1.f - aar) * dalp;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        const float dL_dG = c.w * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * c.x - gdy * c.y;
+                        const float dG_ddely = -gdy * c.z - gdx * c.y;
+                        r[0] = dL_dG * dG_ddelx * ddelx_dx;
+                        r[1] = dL_dG * dG_ddely * ddely_dy;
+                        r[2] = -0.5f * gdx * dx * dL_dG;
+                        r[3] = -gdx * dy * dL_dG;
+                        r[4] = -0.5f * gdy * dy * dL_dG;
+                        r[5] = G * dL_dalpha;
+                    }
+                    const float tot = reduce10(r, lane);
+                    if (my_slot >= 0) s_acc[wave][j][my_slot] = tot;
+                    wrote[c2] |= 1ull << jb;
                 }
-                r0 = wave_sum_to_lane63(r0); r1 = wave_sum_to_lane63(r1); r2 = wave_sum_to_lane63(r2);
-                r3 = wave_sum_to_lane63(r3); r4 = wave_sum_to_lane63(r4); r5 = wave_sum_to_lane63(r5);
-                r6 = wave_sum_to_lane63(r6); r7 = wave_sum_to_lane63(r7); r8 = wave_sum_to_lane63(r8);
-                r9 = wave_sum_to_lane63(r9);
-                if (lane == 63) {
-                    s_acc[wave][j][0] = make_float4(r0, r1, r2, r3);
-                    s_acc[wave][j][1] = make_float4(r4, r5, r6, r7);
-                    s_acc[wave][j][2] = make_float4(r8, r9, 0.f, 0.f);
-                }
-                if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
             }
         }
-        if (lane == 0) { s_mask[wave][0] = m0; s_mask[wave][1] = m1; }
+        __syncthreads();          // every wave has consumed the cull masks
+        if (lane == 0) {
+#pragma unroll
+            for (int c2 = 0; c2 < kBwdBatch / 64; c2++) s_mask[wave][c2] = wrote[c2];
+        }
         __syncthreads();
         // ---- write one record per pair (zeros when no wave touched it); fixed wave order => deterministic ----
         if (tid < cnt) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+            float a[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) a[k] = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const unsigned long long m = s_mask[w][tid >> 6];
                 if ((m >> (tid & 63)) & 1ull) {
-                    const float4 b0 = s_acc[w][tid][0], b1 = s_acc[w][tid][1], b2 = s_acc[w][tid][2];
-                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
-                    a2.x += b2.x; a2.y += b2.y;
+                    const float4 *src = reinterpret_cast<const float4 *>(&s_acc[w][tid][0]);
+                    const float4 b0 = src[0], b1 = src[1], b2 = src[2];
+                    a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w;
+                    a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+                    a[8] += b2.x; a[9] += b2.y;
                 }
             }
             const uint32_t pr = s_pair[tid];
             if (pr < kp.cap) {
-                grad_pair[(size_t)pr * 3] = a0;
-                grad_pair[(size_t)pr * 3 + 1] = a1;
-                grad_pair[(size_t)pr * 3 + 2] = a2;
+                grad_pair[(size_t)pr * 3] = make_float4(a[0], a[1], a[2], a[3]);
+                grad_pair[(size_t)pr * 3 + 1] = make_float4(a[4], a[5], a[6], a[7]);
+                grad_pair[(size_t)pr * 3 + 2] = make_float4(a[8], a[9], 0.f, 0.f);
             }
         }
         __syncthreads();
