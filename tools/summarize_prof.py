@@ -1,0 +1,50 @@
+"""Summarise rocprofv3 CSV output (kernel trace stats + PMC passes) into small text/JSON files."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+raw, out = sys.argv[1], sys.argv[2]
+
+import re
+
+def short(n):
+    m = re.search(r"(k_[a-z_0-9]+)", n)
+    if m:
+        return m.group(1)
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = n.split("(")[0].split("<")[0]
+    return n.split("::")[-1].strip() or "?"
+
+# kernel stats
+for f in glob.glob(os.path.join(raw, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(out, "kernel_stats.txt"), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats summary (times in ns)\n")
+        o.write(f"{'kernel':60s} {'calls':>7s} {'total_ns':>14s} {'avg_ns':>12s} {'pct':>7s} {'min_ns':>10s} {'max_ns':>10s}\n")
+        for r in rows:
+            o.write(f"{short(r['Name'])[:60]:60s} {r['Calls']:>7s} {r['TotalDurationNs']:>14s} {float(r['AverageNs']):12.1f} "
+                    f"{float(r['Percentage']):7.2f} {r['MinNs']:>10s} {r['MaxNs']:>10s}\n")
+    print(open(os.path.join(out, "kernel_stats.txt")).read())
+
+# PMC passes
+summary = {}
+for p in sorted(glob.glob(os.path.join(raw, "pmc*"))):
+    for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(lambda: defaultdict(int))
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+        for k in acc:
+            summary.setdefault(k, {})
+            for c in acc[k]:
+                summary[k][c] = {"avg_per_launch": acc[k][c] / cnt[k][c], "launches": cnt[k][c]}
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+with open(os.path.join(out, "pmc_summary.txt"), "w") as o:
+    for k in summary:
+        if not k.startswith("k_"):
+            continue
+        o.write(k + "\n")
+        for c, v in sorted(summary[k].items()):
+            o.write(f"    {c:28s} {v['avg_per_launch']:18.1f}  (n={v['launches']})\n")
+print(open(os.path.join(out, "pmc_summary.txt")).read())

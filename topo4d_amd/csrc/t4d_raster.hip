@@ -38,6 +38,9 @@ constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave
 constexpr int kFwdBatch = 256;       // splats staged in LDS per round of the forward blend
 constexpr int kBwdBatch = 128;       // splats staged per round of the backward replay
 constexpr int kSortLdsCap = 4096;    // keys sorted in LDS (32 KiB); longer bins use the global-memory path
+constexpr int kRankSortMax = 512;    // bins up to this length are sorted by counting ranks (no barriers)
+constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
+constexpr int kBuckets = 24;         // tile-length classes (floor(log2 n), descending; last = empty) for launch ordering
 constexpr int kGP = T4D_GRAD_PAIR_FLOATS;
 
 thread_local char g_err[512] = "";
@@ -54,8 +57,8 @@ std::vector<ProfRec> g_prof;
 // state / scratch layout
 // ---------------------------------------------------------------------------------------------------------
 struct Layout {
-    size_t status, view_total, view_cursor, tile_count, tile_cursor, zero_end;
-    size_t tile_off, xy, depth, conic_opacity, rgb, clamped, pair_off, keys, final_T, n_contrib, total;
+    size_t status, view_total, view_cursor, tile_count, bucket_fill, zero_end;
+    size_t tile_off, order, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, final_T, n_contrib, total;
 };
 
 struct DevStatus {            // first bytes of the state buffer
@@ -78,15 +81,17 @@ Layout make_layout(const T4DProblem &p)
     L.view_total = o;    o = align_up(o + V * 4);
     L.view_cursor = o;   o = align_up(o + V * 4);
     L.tile_count = o;    o = align_up(o + V * T * 4);
-    L.tile_cursor = o;   o = align_up(o + V * T * 4);
+    L.bucket_fill = o;   o = align_up(o + kBuckets * 4);
     L.zero_end = o;
     L.tile_off = o;      o = align_up(o + V * T * 4);
+    L.order = o;         o = align_up(o + (size_t)kBuckets * V * T * 4);
     L.xy = o;            o = align_up(o + V * P * 8);
     L.depth = o;         o = align_up(o + V * P * 4);
     L.conic_opacity = o; o = align_up(o + V * P * 16);
     L.rgb = o;           o = align_up(o + (p.sh_coeffs > 0 ? V * P * 12 : 0));
     L.clamped = o;       o = align_up(o + (p.sh_coeffs > 0 ? V * P : 0));
     L.pair_off = o;      o = align_up(o + V * P * 4);
+    L.pair_rank = o;     o = align_up(o + V * cap * 4);
     L.keys = o;          o = align_up(o + V * cap * 8);
     L.final_T = o;       o = align_up(o + V * HW * 4);
     L.n_contrib = o;     o = align_up(o + V * HW * 4);
@@ -104,7 +109,7 @@ struct KP {
     const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
     // state
     DevStatus *status;
-    uint32_t *view_total, *view_cursor, *tile_count, *tile_cursor, *tile_off, *pair_off;
+    uint32_t *view_total, *view_cursor, *tile_count, *bucket_fill, *tile_off, *order, *pair_off, *pair_rank;
     float2 *xy;
     float *depth;
     float4 *conic_opacity;
@@ -295,6 +300,8 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
 #pragma clang fp contract(off)
     __shared__ uint32_t s_wave_tot[4];
     __shared__ uint32_t s_base;
+    __shared__ int s_bb[4];
+    __shared__ uint32_t s_hist[kHist], s_hbase[kHist];
     const int tid = threadIdx.x;
     const int g = blockIdx.x * kBlock + tid;
     const int v = blockIdx.y;
@@ -373,10 +380,11 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
         kp.radii[vg] = radius;
     }
 
-    // pair-slot allocation: block-local exclusive scan, ONE returning atomic per workgroup on the view's cursor
+    // ---- pair slots: block-local exclusive scan, ONE returning atomic per workgroup on the view's cursor ----
     const uint32_t incl = wave_incl_scan(tiles);
     const int wave = tid >> 6, lane = tid & 63;
     if (lane == 63) s_wave_tot[wave] = incl;
+    if (tid == 0) { s_bb[0] = 0x7fffffff; s_bb[1] = 0x7fffffff; s_bb[2] = 0; s_bb[3] = 0; }
     __syncthreads();
     uint32_t wave_off = 0, block_tot = 0;
 #pragma unroll
@@ -385,25 +393,92 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
         if (w < wave) wave_off += t;
         block_tot += t;
     }
-    if (tid == 0) s_base = block_tot ? atomicAdd(&kp.view_cursor[v], block_tot) : 0u;
+    if (block_tot == 0) {                                     // workgroup-uniform: nothing visible here
+        if (g < kp.P) kp.pair_off[vg] = 0;
+        return;
+    }
+    if (tid == 0) s_base = atomicAdd(&kp.view_cursor[v], block_tot);
+    {   // bounding box (in tiles) of everything this workgroup touches
+        int bx0 = tiles ? x0 : 0x7fffffff, by0 = tiles ? y0 : 0x7fffffff, bx1 = tiles ? x1 : 0, by1 = tiles ? y1 : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, d, 64)); by0 = min(by0, __shfl_xor(by0, d, 64));
+            bx1 = max(bx1, __shfl_xor(bx1, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+        }
+        if (lane == 0) { atomicMin(&s_bb[0], bx0); atomicMin(&s_bb[1], by0); atomicMax(&s_bb[2], bx1); atomicMax(&s_bb[3], by1); }
+    }
     __syncthreads();
-    if (g < kp.P) kp.pair_off[vg] = s_base + wave_off + incl - tiles;
+    const uint32_t pbase = s_base + wave_off + incl - tiles;
+    if (g < kp.P) kp.pair_off[vg] = pbase;
 
-    // per-tile counts
-    if (tiles) {
-        uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
+    // ---- per-tile counts and the rank of every pair inside its tile ----
+    // Gaussians of one workgroup are usually neighbours on the mesh, so they hit few distinct tiles: count them in an
+    // LDS histogram over the workgroup's tile bounding box and send ONE returning global atomic per touched tile
+    // (instead of one per pair).  Bounding boxes larger than the histogram fall back to per-pair global atomics.
+    uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
+    uint32_t *prank = kp.pair_rank + (size_t)v * kp.cap;
+    const int bbx = s_bb[0], bby = s_bb[1], bw = s_bb[2] - s_bb[0], bh = s_bb[3] - s_bb[1];
+    const int area = bw * bh;
+    if (area <= kHist) {
+        for (int i = tid; i < area; i += kBlock) s_hist[i] = 0;
+        __syncthreads();
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) atomicAdd(&cnt[y * kp.gx + x], 1u);
+            for (int x = x0; x < x1; x++) atomicAdd(&s_hist[(y - bby) * bw + (x - bbx)], 1u);
+        __syncthreads();
+        for (int i = tid; i < area; i += kBlock) {
+            const uint32_t c = s_hist[i];
+            const int ty = i / bw, tx = i - ty * bw;
+            s_hbase[i] = c ? atomicAdd(&cnt[(bby + ty) * kp.gx + bbx + tx], c) : 0u;
+            s_hist[i] = 0;
+        }
+        __syncthreads();
+        uint32_t pr = pbase;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++, pr++) {
+                const int i = (y - bby) * bw + (x - bbx);
+                const uint32_t r = s_hbase[i] + atomicAdd(&s_hist[i], 1u);
+                if (pr < kp.cap) prank[pr] = r;
+            }
+    } else {
+        uint32_t pr = pbase;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++, pr++) {
+                const uint32_t r = atomicAdd(&cnt[y * kp.gx + x], 1u);
+                if (pr < kp.cap) prank[pr] = r;
+            }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // A.2 per-view exclusive scan of tile counts
 // ---------------------------------------------------------------------------------------------------------
+// launch-order class of a tile: longest lists first, empty tiles last
+__device__ __forceinline__ int count_bucket(const uint32_t c)
+{
+    if (c == 0) return kBuckets - 1;
+    return (kBuckets - 2) - min(kBuckets - 2, 31 - __clz((int)c));
+}
+
+// Per-tile kernels use a 1-D grid of V*T workgroups; workgroup b takes the b-th entry of the length-ordered tile list
+// (heavy tiles start first and consecutive heavy tiles land on different XCDs, since block b runs on XCD b % 8).
+__device__ __forceinline__ void locate_tile(const KP &kp, const uint32_t b, int &v, int &t)
+{
+    uint32_t acc = 0, id = 0;
+    const size_t VT = (size_t)kp.V * kp.T;
+    for (int k = 0; k < kBuckets; k++) {
+        const uint32_t c = kp.bucket_fill[k];
+        if (b < acc + c) { id = kp.order[(size_t)k * VT + (b - acc)]; break; }
+        acc += c;
+    }
+    v = (int)(id >> 20);
+    t = (int)(id & 0xfffffu);
+}
+
 __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
 {
     __shared__ uint32_t s_wave_tot[16];
     __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_bcnt[kBuckets], s_bbase[kBuckets];
     const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
     uint32_t *off = kp.tile_off + (size_t)v * kp.T;
@@ -424,8 +499,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
         }
         const uint32_t carry = s_carry;
         if (t < kp.T) off[t] = carry + woff + incl - c;
+        if (tid < kBuckets) s_bcnt[tid] = 0;
         __syncthreads();
         if (tid == 0) s_carry = carry + tot;
+        // launch order: bucket the tiles of this chunk by list length
+        const int bk = count_bucket(c);
+        uint32_t r = 0;
+        if (t < kp.T) r = atomicAdd(&s_bcnt[bk], 1u);
+        __syncthreads();
+        if (tid < kBuckets) s_bbase[tid] = s_bcnt[tid] ? atomicAdd(&kp.bucket_fill[tid], s_bcnt[tid]) : 0u;
+        __syncthreads();
+        if (t < kp.T) kp.order[(size_t)bk * kp.V * kp.T + s_bbase[bk] + r] = ((uint32_t)v << 20) | (uint32_t)t;
         __syncthreads();
     }
     if (tid == 0) {
@@ -452,13 +536,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
     int x0, y0, x1, y1;
     tile_rect(p.x, p.y, r, kp.gx, kp.gy, x0, y0, x1, y1);
     const unsigned long long key = ((unsigned long long)__float_as_uint(kp.depth[vg]) << 32) | (uint32_t)g;
-    uint32_t *cur = kp.tile_cursor + (size_t)v * kp.T;
     const uint32_t *off = kp.tile_off + (size_t)v * kp.T;
+    const uint32_t *prank = kp.pair_rank + (size_t)v * kp.cap;
     unsigned long long *keys = kp.keys + (size_t)v * kp.cap;
+    uint32_t pr = kp.pair_off[vg];
     for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const int t = y * kp.gx + x;
-            const uint32_t pos = off[t] + atomicAdd(&cur[t], 1u);
+        for (int x = x0; x < x1; x++, pr++) {
+            if (pr >= kp.cap) return;
+            const uint32_t pos = off[y * kp.gx + x] + prank[pr];     // rank inside the tile was fixed by k_preprocess
             if (pos < kp.cap) keys[pos] = key;
         }
 }
@@ -476,8 +561,8 @@ __device__ __forceinline__ void bitonic_any_n(Ptr a, const uint32_t n, const int
         // flip stage: i <-> block_end - 1 - (i - block_start)
         for (uint32_t p = tid; p < half; p += kBlock) {
             const uint32_t hb = k >> 1;
-            const uint32_t blk = p / hb, o = p - blk * hb;
-            const uint32_t i = blk * k + o, j = blk * k + k - 1 - o;
+            const uint32_t o = p & (hb - 1), blk2 = (p - o) << 1;      // blk * k  (hb is a power of two)
+            const uint32_t i = blk2 + o, j = blk2 + k - 1 - o;
             if (j < n) {
                 const unsigned long long x = a[i], y = a[j];
                 if (x > y) { a[i] = y; a[j] = x; }
@@ -501,7 +586,9 @@ __device__ __forceinline__ void bitonic_any_n(Ptr a, const uint32_t n, const int
 __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 {
     __shared__ unsigned long long s_keys[kSortLdsCap];
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int v, t;
+    locate_tile(kp, blockIdx.x, v, t);
     const size_t vt = (size_t)v * kp.T + t;
     const uint32_t off = kp.tile_off[vt];
     uint32_t n = kp.tile_count[vt];
@@ -509,7 +596,29 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
     n = min(n, kp.cap - off);
     if (n < 2) return;
     unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-    if (n <= (uint32_t)kSortLdsCap) {
+    if (n <= (uint32_t)kRankSortMax) {
+        // counting sort by rank: keys are unique (index in the low word), so rank = #keys smaller than mine.
+        // One barrier, every LDS read is a wave-wide broadcast.
+        unsigned long long mine[kRankSortMax / kBlock];
+#pragma unroll
+        for (int e = 0; e < kRankSortMax / kBlock; e++) {
+            const uint32_t i = tid + e * kBlock;
+            mine[e] = i < n ? keys[i] : ~0ull;
+            if (i < n) s_keys[i] = mine[e];
+        }
+        __syncthreads();
+        uint32_t rank[kRankSortMax / kBlock];
+#pragma unroll
+        for (int e = 0; e < kRankSortMax / kBlock; e++) rank[e] = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const unsigned long long k = s_keys[i];
+#pragma unroll
+            for (int e = 0; e < kRankSortMax / kBlock; e++) rank[e] += k < mine[e] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < kRankSortMax / kBlock; e++)
+            if (tid + e * kBlock < n) keys[rank[e]] = mine[e];
+    } else if (n <= (uint32_t)kSortLdsCap) {
         for (uint32_t i = tid; i < n; i += kBlock) s_keys[i] = keys[i];
         __syncthreads();
         bitonic_any_n(s_keys, n, tid);
@@ -594,9 +703,12 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
     __shared__ float4 s_q[kFwdBatch];    // scaled conic + opacity
     __shared__ float4 s_cd[kFwdBatch];   // rgb + depth
     __shared__ unsigned long long s_mask[4][kFwdBatch / 64];
-    const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int v, t_;
+    locate_tile(kp, blockIdx.x, v, t_);
+    const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const int wave = tid >> 6, lane = tid & 63;
-    const size_t vt = (size_t)v * kp.T + (size_t)ty * kp.gx + tx;
+    const size_t vt = (size_t)v * kp.T + t_;
     const uint32_t off = kp.tile_off[vt];
     uint32_t n = kp.tile_count[vt];
     n = off >= kp.cap ? 0u : min(n, kp.cap - off);
@@ -749,9 +861,12 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
     __shared__ unsigned long long s_mask[4][kBwdBatch / 64];   // cull masks (in), then "slab written" masks (out)
     __shared__ uint32_t s_wmax[4];
 
-    const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int v, t_;
+    locate_tile(kp, blockIdx.x, v, t_);
+    const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const int wave = tid >> 6, lane = tid & 63;
-    const size_t vt = (size_t)v * kp.T + (size_t)ty * kp.gx + tx;
+    const size_t vt = (size_t)v * kp.T + t_;
     const uint32_t off = kp.tile_off[vt];
     uint32_t n = kp.tile_count[vt];
     n = off >= kp.cap ? 0u : min(n, kp.cap - off);
@@ -1145,7 +1260,9 @@ int check_problem(const T4DProblem *p)
     if (!p) return fail(T4D_ERR_ARG, "null problem");
     if (p->abi_version != T4D_ABI_VERSION) return fail(T4D_ERR_ARG, "abi_version mismatch");
     if (p->n_views < 1 || p->P < 1 || p->H < 1 || p->W < 1) return fail(T4D_ERR_ARG, "n_views, P, H, W must be >= 1");
-    if (p->n_views > 65535) return fail(T4D_ERR_ARG, "n_views must be <= 65535");
+    if (p->n_views > 4095) return fail(T4D_ERR_ARG, "n_views must be <= 4095");
+    if ((int64_t)((p->W + T4D_TILE_X - 1) / T4D_TILE_X) * ((p->H + T4D_TILE_Y - 1) / T4D_TILE_Y) > 0xfffff)
+        return fail(T4D_ERR_ARG, "image too large: more than 2^20 tiles");
     if (p->pair_capacity < 1 || p->pair_capacity > 0x7fffffffLL) return fail(T4D_ERR_ARG, "pair_capacity out of range");
     if (p->sh_coeffs < 0 || p->sh_degree < 0 || p->sh_degree > 3) return fail(T4D_ERR_ARG, "sh_degree must be 0..3");
     if (p->sh_coeffs > 0 && p->sh_coeffs < (p->sh_degree + 1) * (p->sh_degree + 1))
@@ -1166,7 +1283,9 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.view_total = reinterpret_cast<uint32_t *>(st + L.view_total);
     kp.view_cursor = reinterpret_cast<uint32_t *>(st + L.view_cursor);
     kp.tile_count = reinterpret_cast<uint32_t *>(st + L.tile_count);
-    kp.tile_cursor = reinterpret_cast<uint32_t *>(st + L.tile_cursor);
+    kp.bucket_fill = reinterpret_cast<uint32_t *>(st + L.bucket_fill);
+    kp.order = reinterpret_cast<uint32_t *>(st + L.order);
+    kp.pair_rank = reinterpret_cast<uint32_t *>(st + L.pair_rank);
     kp.tile_off = reinterpret_cast<uint32_t *>(st + L.tile_off);
     kp.pair_off = reinterpret_cast<uint32_t *>(st + L.pair_off);
     kp.xy = reinterpret_cast<float2 *>(st + L.xy);
@@ -1207,7 +1326,7 @@ T4D_EXPORT int t4d_debug_state_layout(const T4DProblem *prob, int has_sh, uint64
     T4DProblem p = *prob;
     if (!has_sh) p.sh_coeffs = 0;
     const Layout L = make_layout(p);
-    const size_t f[T4D_DEBUG_LAYOUT_FIELDS] = { L.status, L.view_total, L.view_cursor, L.tile_count, L.tile_cursor, L.tile_off,
+    const size_t f[T4D_DEBUG_LAYOUT_FIELDS] = { L.status, L.view_total, L.view_cursor, L.tile_count, L.bucket_fill, L.tile_off,
                                                 L.xy, L.depth, L.conic_opacity, L.rgb, L.clamped, L.pair_off, L.keys,
                                                 L.final_T, L.n_contrib, L.total };
     for (int i = 0; i < T4D_DEBUG_LAYOUT_FIELDS; i++) offsets[i] = (uint64_t)f[i];
@@ -1270,11 +1389,11 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     }
     T4D_LAUNCH_CHECK("k_scatter");
     { ProfScope ps_(stream, K_SORT_TILES);
-    hipLaunchKernelGGL(k_sort_tiles, dim3(kp.T, p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
-    hipLaunchKernelGGL(k_render_fwd, dim3(kp.gx, kp.gy, p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_render_fwd, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
     return T4D_OK;
@@ -1318,7 +1437,7 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
 
     { ProfScope ps_(stream, K_RENDER_BWD);
-    hipLaunchKernelGGL(k_render_bwd, dim3(kp.gx, kp.gy, p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_render_bwd, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
