@@ -25,6 +25,24 @@ for f in glob.glob(os.path.join(raw, "trace", "**", "*kernel_stats.csv"), recurs
                     f"{float(r['Percentage']):7.2f} {r['MinNs']:>10s} {r['MaxNs']:>10s}\n")
     print(open(os.path.join(out, "kernel_stats.txt")).read())
 
+# timeline of one step: gaps between consecutive kernels (from the kernel trace)
+for f in glob.glob(os.path.join(raw, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # find the last occurrence of k_preprocess .. next k_preprocess
+    idx = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_preprocess"]
+    if len(idx) >= 3:
+        a, b = idx[-3], idx[-2]
+        with open(os.path.join(out, "step_timeline.txt"), "w") as o:
+            o.write("# one steady-state step: kernel, start offset (us), duration (us), gap to previous kernel end (us)\n")
+            t0 = int(rows[a]["Start_Timestamp"]); prev_end = None
+            for r in rows[a:b + 1]:
+                st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                gap = 0.0 if prev_end is None else (st - prev_end) / 1e3
+                o.write(f"{short(r['Kernel_Name'])[:40]:40s} {(st - t0) / 1e3:10.1f} {(en - st) / 1e3:10.1f} {gap:8.1f}\n")
+                prev_end = en
+        print(open(os.path.join(out, "step_timeline.txt")).read())
+
 # PMC passes
 summary = {}
 for p in sorted(glob.glob(os.path.join(raw, "pmc*"))):

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -58,7 +59,7 @@ std::vector<ProfRec> g_prof;
 // ---------------------------------------------------------------------------------------------------------
 struct Layout {
     size_t status, view_total, view_cursor, tile_count, bucket_fill, zero_end;
-    size_t tile_off, order, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, final_T, n_contrib, total;
+    size_t tile_off, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, final_T, n_contrib, total;
 };
 
 struct DevStatus {            // first bytes of the state buffer
@@ -85,6 +86,7 @@ Layout make_layout(const T4DProblem &p)
     L.zero_end = o;
     L.tile_off = o;      o = align_up(o + V * T * 4);
     L.order = o;         o = align_up(o + (size_t)kBuckets * V * T * 4);
+    L.items = o;         o = align_up(o + V * T * 16);
     L.xy = o;            o = align_up(o + V * P * 8);
     L.depth = o;         o = align_up(o + V * P * 4);
     L.conic_opacity = o; o = align_up(o + V * P * 16);
@@ -110,6 +112,7 @@ struct KP {
     // state
     DevStatus *status;
     uint32_t *view_total, *view_cursor, *tile_count, *bucket_fill, *tile_off, *order, *pair_off, *pair_rank;
+    uint4 *items;
     float2 *xy;
     float *depth;
     float4 *conic_opacity;
@@ -459,19 +462,30 @@ __device__ __forceinline__ int count_bucket(const uint32_t c)
     return (kBuckets - 2) - min(kBuckets - 2, 31 - __clz((int)c));
 }
 
-// Per-tile kernels use a 1-D grid of V*T workgroups; workgroup b takes the b-th entry of the length-ordered tile list
-// (heavy tiles start first and consecutive heavy tiles land on different XCDs, since block b runs on XCD b % 8).
-__device__ __forceinline__ void locate_tile(const KP &kp, const uint32_t b, int &v, int &t)
+// Per-tile kernels are PERSISTENT: a fixed grid of (CUs x resident workgroups) loops over the length-ordered tile
+// list, item b -> workgroup b % gridDim.x.  Heavy tiles start first and consecutive heavy tiles land on different
+// XCDs (block b runs on XCD b % 8); empty tiles cost no workgroup launch and no dependent-load chain.
+struct TileOrder {
+    uint32_t pre[kBuckets + 1];     // exclusive prefix of the bucket totals (wave-uniform, lives in SGPRs)
+};
+
+__device__ __forceinline__ void load_tile_order(const KP &kp, TileOrder &o)
 {
-    uint32_t acc = 0, id = 0;
-    const size_t VT = (size_t)kp.V * kp.T;
+    uint32_t acc = 0;
+#pragma unroll
     for (int k = 0; k < kBuckets; k++) {
-        const uint32_t c = kp.bucket_fill[k];
-        if (b < acc + c) { id = kp.order[(size_t)k * VT + (b - acc)]; break; }
-        acc += c;
+        o.pre[k] = acc;
+        acc += kp.bucket_fill[k];
     }
-    v = (int)(id >> 20);
-    t = (int)(id & 0xfffffu);
+    o.pre[kBuckets] = acc;
+}
+
+__device__ __forceinline__ uint32_t tile_order_id(const KP &kp, const TileOrder &o, const uint32_t b)
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < kBuckets; i++) k += b >= o.pre[i] ? 1 : 0;
+    return kp.order[(size_t)k * kp.V * kp.T + (b - o.pre[k])];      // (view << 20) | tile
 }
 
 __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
@@ -526,6 +540,22 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
 {
+    const int n_pblocks = (kp.P + kBlock - 1) / kBlock;
+    if ((int)blockIdx.x >= n_pblocks) {
+        // Tail blocks of this launch: flatten the length-ordered tile list into one 16-byte record per work item,
+        // items[b] = (view << 20 | tile, arena offset, list length, -), so that a per-tile workgroup starts with ONE
+        // scalar load instead of a chain of dependent loads (there are ~25k such workgroups per launch).
+        const uint32_t b = ((uint32_t)blockIdx.y * (gridDim.x - n_pblocks) + (blockIdx.x - n_pblocks)) * kBlock + threadIdx.x;
+        if (b >= (uint32_t)(kp.V * kp.T)) return;
+        TileOrder ord;
+        load_tile_order(kp, ord);
+        const uint32_t id = tile_order_id(kp, ord, b);
+        const size_t vt = (size_t)(id >> 20) * kp.T + (id & 0xfffffu);
+        const uint32_t off = kp.tile_off[vt];
+        const uint32_t n = off >= kp.cap ? 0u : min(kp.tile_count[vt], kp.cap - off);
+        kp.items[b] = make_uint4(id, off, n, 0u);
+        return;
+    }
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int v = blockIdx.y;
     if (g >= kp.P) return;
@@ -587,46 +617,50 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 {
     __shared__ unsigned long long s_keys[kSortLdsCap];
     const int tid = threadIdx.x;
-    int v, t;
-    locate_tile(kp, blockIdx.x, v, t);
-    const size_t vt = (size_t)v * kp.T + t;
-    const uint32_t off = kp.tile_off[vt];
-    uint32_t n = kp.tile_count[vt];
-    if (off >= kp.cap) return;
-    n = min(n, kp.cap - off);
-    if (n < 2) return;
-    unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-    if (n <= (uint32_t)kRankSortMax) {
-        // counting sort by rank: keys are unique (index in the low word), so rank = #keys smaller than mine.
-        // One barrier, every LDS read is a wave-wide broadcast.
-        unsigned long long mine[kRankSortMax / kBlock];
+    const uint32_t n_items = (uint32_t)(kp.V * kp.T);
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint4 it = kp.items[item];
+        const int v = (int)(it.x >> 20);
+        const uint32_t off = it.y, n = it.z;
+        if (n < 2) break;                                          // items are ordered by length: nothing left
+        unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+        if (n <= (uint32_t)kRankSortMax) {
+            // counting sort by rank: keys are unique (index in the low word), so rank = #keys smaller than mine.
+            // One barrier, every LDS read is a wave-wide broadcast.
+            unsigned long long mine[kRankSortMax / kBlock];
 #pragma unroll
-        for (int e = 0; e < kRankSortMax / kBlock; e++) {
-            const uint32_t i = tid + e * kBlock;
-            mine[e] = i < n ? keys[i] : ~0ull;
-            if (i < n) s_keys[i] = mine[e];
+            for (int e = 0; e < kRankSortMax / kBlock; e++) {
+                const uint32_t i = tid + e * kBlock;
+                mine[e] = i < n ? keys[i] : ~0ull;
+                s_keys[i] = mine[e];                              // padded with +inf up to kRankSortMax
+            }
+            __syncthreads();
+            uint32_t rank[kRankSortMax / kBlock];
+#pragma unroll
+            for (int e = 0; e < kRankSortMax / kBlock; e++) rank[e] = 0;
+            const uint32_t n4 = (n + 3u) & ~3u;
+            for (uint32_t i = 0; i < n4; i += 4) {
+                const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&s_keys[i]);
+                const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&s_keys[i + 2]);
+#pragma unroll
+                for (int e = 0; e < kRankSortMax / kBlock; e++)
+                    rank[e] += (ka.x < mine[e] ? 1u : 0u) + (ka.y < mine[e] ? 1u : 0u) + (kb.x < mine[e] ? 1u : 0u) +
+                               (kb.y < mine[e] ? 1u : 0u);
+            }
+#pragma unroll
+            for (int e = 0; e < kRankSortMax / kBlock; e++)
+                if (tid + e * kBlock < n) keys[rank[e]] = mine[e];
+        } else if (n <= (uint32_t)kSortLdsCap) {
+            for (uint32_t i = tid; i < n; i += kBlock) s_keys[i] = keys[i];
+            __syncthreads();
+            bitonic_any_n(s_keys, n, tid);
+            for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
+        } else {
+            // rare: a bin longer than the LDS buffer is sorted in place in global memory by this workgroup
+            // (same network; __syncthreads() orders the workgroup's own global accesses through its CU's L1/L2)
+            bitonic_any_n(keys, n, tid);
         }
-        __syncthreads();
-        uint32_t rank[kRankSortMax / kBlock];
-#pragma unroll
-        for (int e = 0; e < kRankSortMax / kBlock; e++) rank[e] = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            const unsigned long long k = s_keys[i];
-#pragma unroll
-            for (int e = 0; e < kRankSortMax / kBlock; e++) rank[e] += k < mine[e] ? 1u : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < kRankSortMax / kBlock; e++)
-            if (tid + e * kBlock < n) keys[rank[e]] = mine[e];
-    } else if (n <= (uint32_t)kSortLdsCap) {
-        for (uint32_t i = tid; i < n; i += kBlock) s_keys[i] = keys[i];
-        __syncthreads();
-        bitonic_any_n(s_keys, n, tid);
-        for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
-    } else {
-        // rare: a bin longer than the LDS buffer is sorted in place in global memory by this workgroup
-        // (same network; __syncthreads() orders the workgroup's own global accesses through its CU's L1/L2)
-        bitonic_any_n(keys, n, tid);
+        __syncthreads();                                           // s_keys is reused by the next item
     }
 }
 
@@ -697,21 +731,49 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Expand a wave's four 64-bit visit masks into a compact list of staged-splat indices (ascending when !REVERSE,
+// descending when REVERSE), padded with kNull entries so the consumer can always read groups of four.  The
+// hot loops then are plain counted loops: almost no scalar-unit work per splat (the CU's single scalar unit is
+// what bounded the first version of these kernels).
+template <int NCHUNK, bool REVERSE>
+__device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NCHUNK], unsigned short *list, const int lane,
+                                                const unsigned short null_idx)
+{
+    int cnt = 0;
+#pragma unroll
+    for (int cc = 0; cc < NCHUNK; cc++) {
+        const int c = REVERSE ? NCHUNK - 1 - cc : cc;
+        const unsigned long long mw = m[c];
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
+        const int tot = __builtin_popcountll(mw);
+        if ((mw >> lane) & 1ull) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)((c << 6) + lane);
+        cnt += tot;
+    }
+    if (lane < 4) list[cnt + lane] = null_idx;
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
 __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
 {
-    __shared__ float2 s_xy[kFwdBatch];
-    __shared__ float4 s_q[kFwdBatch];    // scaled conic + opacity
-    __shared__ float4 s_cd[kFwdBatch];   // rgb + depth
+    constexpr int kNull = kFwdBatch;                 // staged slot that can never contribute (opacity 0)
+    __shared__ float2 s_xy[kFwdBatch + 1];
+    __shared__ float4 s_q[kFwdBatch + 1];            // scaled conic + opacity
+    __shared__ float4 s_cd[kFwdBatch + 1];           // rgb + depth
     __shared__ unsigned long long s_mask[4][kFwdBatch / 64];
+    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][kFwdBatch + 4];
     const int tid = threadIdx.x;
-    int v, t_;
-    locate_tile(kp, blockIdx.x, v, t_);
-    const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const int wave = tid >> 6, lane = tid & 63;
-    const size_t vt = (size_t)v * kp.T + t_;
-    const uint32_t off = kp.tile_off[vt];
-    uint32_t n = kp.tile_count[vt];
-    n = off >= kp.cap ? 0u : min(n, kp.cap - off);
+    if (tid == 0) {
+        s_xy[kNull] = make_float2(0.f, 0.f);
+        s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_cd[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {   // every tile, empty ones last
+    const uint4 it = kp.items[item];
+    const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
+    const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
+    const uint32_t off = it.y, n = it.z;
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
@@ -745,33 +807,44 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
             if (lane == 0) s_mask[w][wave] = bal;
         }
         __syncthreads();
-        if (!__all(done)) {
-            for (int c4 = 0; c4 < kFwdBatch / 64; c4++) {
-                unsigned long long m = uniform_u64(s_mask[wave][c4]);
-                while (m) {
-                    const int j = (c4 << 6) + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float2 g_xy = s_xy[j];
-                    const float4 q = s_q[j];
-                    float p2, G, alpha;
-                    eval_splat(q, g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha);
-                    bool ok = !done && !(p2 > 0.0f) && !(alpha < T4D_ALPHA_MIN);
-                    const float test_T = T * (1.f - alpha);
-                    const bool stop = ok && test_T < T4D_T_STOP;
-                    done = done || stop;
-                    ok = ok && !stop;
-                    if (__any(ok)) {
-                        const float4 cd = s_cd[j];
-                        const float w = ok ? alpha * T : 0.f;
-                        C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
-                        D = fmaf(cd.w, w, D);
-                        Wt += w;
-                        T = ok ? test_T : T;
-                        last_contributor = ok ? b + (uint32_t)j + 1u : last_contributor;
-                    }
-                    if (__all(done)) { m = 0; c4 = kFwdBatch; }
-                }
+        if (__all(done)) continue;                   // wave-uniform; still takes part in the barriers above
+        unsigned long long m[kFwdBatch / 64];
+#pragma unroll
+        for (int c4 = 0; c4 < kFwdBatch / 64; c4++) m[c4] = uniform_u64(s_mask[wave][c4]);
+        unsigned short *list = s_list[wave];
+        const int cnt = build_visit_list<kFwdBatch / 64, false>(m, list, lane, (unsigned short)kNull);
+        for (int k = 0; k < cnt; k += 4) {
+            const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
+            const int j[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
+            float alpha[4];
+            bool valid[4];
+            bool anyv = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                // four independent evaluations: ILP hides LDS / exp latency
+                const float2 g_xy = s_xy[j[u]];
+                float p2, G;
+                eval_splat(s_q[j[u]], g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha[u]);
+                valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
+                anyv = anyv || valid[u];
             }
+            if (!__any(anyv && !done)) continue;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                // blending is sequential in list order
+                bool ok = valid[u] && !done;
+                if (!__any(ok)) continue;
+                const float test_T = T * (1.f - alpha[u]);
+                const bool stop = ok && test_T < T4D_T_STOP;
+                done = done || stop;
+                ok = ok && !stop;
+                const float4 cd = s_cd[j[u]];
+                const float w = ok ? alpha[u] * T : 0.f;
+                C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
+                D = fmaf(cd.w, w, D);
+                Wt += w;
+                T = ok ? test_T : T;
+                last_contributor = ok ? b + (uint32_t)j[u] + 1u : last_contributor;
+            }
+            if (__all(done)) break;
         }
     }
     if (inside) {
@@ -785,6 +858,8 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
         oc[2 * HW + pix] = C2 + T * vr[37];
         kp.out_depth[(size_t)v * HW + pix] = D;
         kp.out_alpha[(size_t)v * HW + pix] = Wt;
+    }
+    __syncthreads();                                 // staging buffers are reused by the next tile
     }
 }
 
@@ -852,25 +927,31 @@ __device__ __forceinline__ int red10_index(const int lane)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
 {
-    __shared__ float2 s_xy[kBwdBatch];
+    __shared__ float2 s_xy[kBwdBatch + 1];
     __shared__ float4 s_co[kBwdBatch];   // raw conic + opacity
-    __shared__ float4 s_q[kBwdBatch];    // scaled conic + opacity (alpha evaluation)
+    __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
     __shared__ float4 s_cd[kBwdBatch];
     __shared__ uint32_t s_pair[kBwdBatch];
     __shared__ float s_acc[4][kBwdBatch][kGP];
     __shared__ unsigned long long s_mask[4][kBwdBatch / 64];   // cull masks (in), then "slab written" masks (out)
     __shared__ uint32_t s_wmax[4];
+    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][kBwdBatch + 4];
+    constexpr int kNull = kBwdBatch;
+    static_assert(kBwdBatch == 128, "the slab-written masks below assume two 64-splat chunks per batch");
 
     const int tid = threadIdx.x;
-    int v, t_;
-    locate_tile(kp, blockIdx.x, v, t_);
-    const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const int wave = tid >> 6, lane = tid & 63;
-    const size_t vt = (size_t)v * kp.T + t_;
-    const uint32_t off = kp.tile_off[vt];
-    uint32_t n = kp.tile_count[vt];
-    n = off >= kp.cap ? 0u : min(n, kp.cap - off);
-    if (n == 0) return;
+    const int my_slot = red10_index(lane);
+    if (tid == 0) {
+        s_xy[kNull] = make_float2(0.f, 0.f);
+        s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {
+    const uint4 it = kp.items[item];
+    const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
+    const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
+    const uint32_t off = it.y, n = it.z;
+    if (n == 0) break;                                             // ordered by length: only empty tiles remain
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
@@ -901,7 +982,6 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
     float adr = 0.f, ldp = 0.f, aar = 0.f, last_alpha = 0.f;
     const float bg_dot = vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2;
     const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
-    const int my_slot = red10_index(lane);
 
     const uint32_t wave_max = wave_max_u32(last_contributor);
     if (lane == 0) s_wmax[wave] = wave_max;
@@ -944,43 +1024,63 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
 #pragma unroll
         for (int c2 = 0; c2 < kBwdBatch / 64; c2++) wrote[c2] = 0ull;
         if (live) {
+            unsigned long long m[kBwdBatch / 64];
 #pragma unroll
-            for (int c2 = kBwdBatch / 64 - 1; c2 >= 0; c2--) {
-                unsigned long long m = uniform_u64(s_mask[wave][c2]);
-                while (m) {
-                    const int jb = 63 - __builtin_clzll(m);
-                    m &= ~(1ull << jb);
-                    const int j = (c2 << 6) + jb;
-                    const uint32_t pos = lo + (uint32_t)j;
-                    if (pos >= wave_max) continue;                 // wave-uniform
-                    const float2 g_xy = s_xy[j];
-                    const float dx = g_xy.x - pxf, dy = g_xy.y - pyf;
-                    float p2, G, alpha;
-                    eval_splat(s_q[j], dx, dy, p2, G, alpha);
-                    const bool contrib = pos < last_contributor && !(p2 > 0.0f) && !(alpha < T4D_ALPHA_MIN);
+            for (int c2 = 0; c2 < kBwdBatch / 64; c2++) {
+                m[c2] = uniform_u64(s_mask[wave][c2]);
+                // positions at or beyond the wave's last contributor cannot matter: drop them from the mask
+                const uint32_t base = lo + ((uint32_t)c2 << 6);
+                if (wave_max <= base) m[c2] = 0;
+                else if (wave_max - base < 64u) m[c2] &= (1ull << (wave_max - base)) - 1ull;
+            }
+            unsigned short *list = s_list[wave];
+            const int nvis = build_visit_list<kBwdBatch / 64, true>(m, list, lane, (unsigned short)kNull);   // back to front
+            for (int k = 0; k < nvis; k += 4) {
+                const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
+                const int jj[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
+                float dxs[4], dys[4], Gs[4], alphas[4];
+                bool contribs[4];
+                bool anyc = false;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
+                    const float2 g_xy = s_xy[jj[u]];
+                    dxs[u] = g_xy.x - pxf; dys[u] = g_xy.y - pyf;
+                    float p2;
+                    eval_splat(s_q[jj[u]], dxs[u], dys[u], p2, Gs[u], alphas[u]);
+                    contribs[u] = lo + (uint32_t)jj[u] < last_contributor && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
+                    anyc = anyc || contribs[u];
+                }
+                if (!__any(anyc)) continue;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool contrib = contribs[u];
                     if (!__any(contrib)) continue;                 // wave-uniform
+                    const int j = __builtin_amdgcn_readfirstlane(jj[u]);
+                    const float dx = dxs[u], dy = dys[u], G = Gs[u], alpha = alphas[u];
                     float r[10];
 #pragma unroll
-                    for (int k = 0; k < 10; k++) r[k] = 0.f;
+                    for (int q = 0; q < 10; q++) r[q] = 0.f;
                     if (contrib) {
                         const float4 c = s_co[j];
                         const float4 cd = s_cd[j];
-                        T = T / (1.f - alpha);
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
+                        T = T * inv;
                         const float dchannel_dcolor = alpha * T;
+                        const float oma = 1.f - last_alpha;
                         float dL_dalpha;
-                        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = cd.x;
-                        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = cd.y;
-                        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = cd.z;
+                        ar0 = fmaf(last_alpha, lc0, oma * ar0); lc0 = cd.x;
+                        ar1 = fmaf(last_alpha, lc1, oma * ar1); lc1 = cd.y;
+                        ar2 = fmaf(last_alpha, lc2, oma * ar2); lc2 = cd.z;
                         dL_dalpha = (cd.x - ar0) * dp0 + (cd.y - ar1) * dp1 + (cd.z - ar2) * dp2;
                         r[6] = dchannel_dcolor * dp0; r[7] = dchannel_dcolor * dp1; r[8] = dchannel_dcolor * dp2;
-                        adr = last_alpha * ldp + (1.f - last_alpha) * adr; ldp = cd.w;
+                        adr = fmaf(last_alpha, ldp, oma * adr); ldp = cd.w;
                         dL_dalpha += (cd.w - adr) * ddep;
                         r[9] = dchannel_dcolor * ddep;
-                        aar = last_alpha + (1.f - last_alpha) * aar;
+                        aar = fmaf(oma, aar, last_alpha);
                         dL_dalpha += (1.f - aar) * dalp;
                         dL_dalpha *= T;
                         last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        dL_dalpha -= T_final * inv * bg_dot;
                         const float dL_dG = c.w * dL_dalpha;
                         const float gdx = G * dx, gdy = G * dy;
                         const float dG_ddelx = -gdx * c.x - gdy * c.y;
@@ -994,7 +1094,8 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
                     }
                     const float tot = reduce10(r, lane);
                     if (my_slot >= 0) s_acc[wave][j][my_slot] = tot;
-                    wrote[c2] |= 1ull << jb;
+                    if (j < 64) wrote[0] |= 1ull << j;
+                    else wrote[kBwdBatch / 64 - 1] |= 1ull << (j - 64);
                 }
             }
         }
@@ -1028,6 +1129,7 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
             }
         }
         __syncthreads();
+    }
     }
 }
 
@@ -1208,6 +1310,42 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// per-view scalar <a, b> (e.g. the loss term sum(colour * dL/dcolour) each rank contributes to the loss gather):
+// one pass over both images, deterministic two-level sum.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kDotBlocks = 64;
+
+__global__ __launch_bounds__(kBlock) void k_view_dot_partial(const float *a, const float *b, size_t n, float *partial)
+{
+    __shared__ float s_w[4];
+    const int v = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const float *pa = a + (size_t)v * n, *pb = b + (size_t)v * n;
+    const size_t per = (((n + kDotBlocks - 1) / kDotBlocks) + 3) & ~(size_t)3;     // multiple of 4
+    const size_t lo = min(n, (size_t)blk * per), hi = min(n, lo + per);
+    float acc = 0.f;
+    if ((n & 3) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0) {               // 16-byte loads
+        for (size_t i = lo + (size_t)tid * 4; i < hi; i += (size_t)kBlock * 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(pa + i), y = *reinterpret_cast<const float4 *>(pb + i);
+            acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+    } else {
+        for (size_t k = lo + tid; k < hi; k += kBlock) acc += pa[k] * pb[k];
+    }
+    acc = wave_sum_to_lane63(acc);
+    if ((tid & 63) == 63) s_w[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)v * kDotBlocks + blk] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(64) void k_view_dot_final(const float *partial, float *out)
+{
+    const int v = blockIdx.x;
+    float x = partial[(size_t)v * kDotBlocks + threadIdx.x];
+    x = wave_sum_to_lane63(x);
+    if (threadIdx.x == 63) out[v] = x;
+}
+
 __global__ __launch_bounds__(kBlock) void k_mark_visible(int P, const float *means3D, const float *view, uint8_t *present)
 {
 #pragma clang fp contract(off)
@@ -1255,6 +1393,32 @@ struct ProfScope {
         }                                                                                      \
     } while (0)
 
+int device_cus()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;                                             // MI355X
+        cus = n;
+    }
+    return cus;
+}
+
+// Grid of the per-tile kernels.  They are written as grid-stride loops over the length-ordered tile list, but on
+// MI355X one workgroup per tile (the hardware dispatcher balancing the load dynamically) measured 1.4x faster
+// than a resident grid with static striding, so the default is the full grid.  T4D_PERSISTENT=1 selects the
+// resident grid (CUs x per_cu workgroups) for experiments.
+int tile_grid(int n_tiles, int per_cu)
+{
+    static int persistent = -1;
+    if (persistent < 0) {
+        const char *e = getenv("T4D_PERSISTENT");
+        persistent = (e && e[0] == '1') ? 1 : 0;
+    }
+    return persistent ? min(n_tiles, device_cus() * per_cu) : n_tiles;
+}
+
 int check_problem(const T4DProblem *p)
 {
     if (!p) return fail(T4D_ERR_ARG, "null problem");
@@ -1285,6 +1449,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.tile_count = reinterpret_cast<uint32_t *>(st + L.tile_count);
     kp.bucket_fill = reinterpret_cast<uint32_t *>(st + L.bucket_fill);
     kp.order = reinterpret_cast<uint32_t *>(st + L.order);
+    kp.items = reinterpret_cast<uint4 *>(st + L.items);
     kp.pair_rank = reinterpret_cast<uint32_t *>(st + L.pair_rank);
     kp.tile_off = reinterpret_cast<uint32_t *>(st + L.tile_off);
     kp.pair_off = reinterpret_cast<uint32_t *>(st + L.pair_off);
@@ -1385,15 +1550,15 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         if (hs.overflow) return fail(T4D_ERR_PAIR_OVERFLOW, "pair_capacity too small for this scene");
     }
     { ProfScope ps_(stream, K_SCATTER);
-    hipLaunchKernelGGL(k_scatter, gP, dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_scatter, dim3(gP.x + (kp.T + kBlock - 1) / kBlock, p.n_views), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_scatter");
     { ProfScope ps_(stream, K_SORT_TILES);
-    hipLaunchKernelGGL(k_sort_tiles, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(tile_grid(kp.T * p.n_views, 5)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
-    hipLaunchKernelGGL(k_render_fwd, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_render_fwd, dim3(tile_grid(kp.T * p.n_views, 6)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
     return T4D_OK;
@@ -1437,7 +1602,7 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
 
     { ProfScope ps_(stream, K_RENDER_BWD);
-    hipLaunchKernelGGL(k_render_bwd, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_render_bwd, dim3(tile_grid(kp.T * p.n_views, 4)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
@@ -1491,6 +1656,22 @@ T4D_EXPORT int t4d_fetch_status(const T4DProblem *prob, const void *state, T4DSt
     out->total_pairs = (int64_t)hs.total_pairs;
     out->overflow = (int32_t)hs.overflow;
     out->reserved = 0;
+    return T4D_OK;
+}
+
+T4D_EXPORT size_t t4d_view_dot_scratch_bytes(int32_t n_views) { return n_views > 0 ? (size_t)n_views * kDotBlocks * sizeof(float) : 0; }
+
+T4D_EXPORT int t4d_view_dot(int32_t n_views, int64_t n_per_view, const float *a, const float *b, float *out, void *scratch,
+                            void *hip_stream)
+{
+    if (n_views < 1 || n_per_view < 1 || !a || !b || !out || !scratch) return fail(T4D_ERR_ARG, "bad arguments");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool debug = false;
+    hipLaunchKernelGGL(k_view_dot_partial, dim3(kDotBlocks, n_views), dim3(kBlock), 0, stream, a, b, (size_t)n_per_view,
+                       (float *)scratch);
+    T4D_LAUNCH_CHECK("k_view_dot_partial");
+    hipLaunchKernelGGL(k_view_dot_final, dim3(n_views), dim3(64), 0, stream, (const float *)scratch, out);
+    T4D_LAUNCH_CHECK("k_view_dot_final");
     return T4D_OK;
 }
 

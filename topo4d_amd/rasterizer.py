@@ -294,6 +294,24 @@ class ViewBatch:
         return st
 
 
+def view_dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[v] = sum(a[v] * b[v]) in one fused, deterministic pass (t4d_view_dot).  a, b: [V, ...] fp32 on the GPU."""
+    if not a.is_cuda or a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("view_dot needs two fp32 HIP tensors of the same shape")
+    lib = _lib.load()
+    a, b = a.contiguous(), b.contiguous()
+    V = int(a.shape[0])
+    n = a.numel() // V
+    if out is None:
+        out = torch.empty(V, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(lib.t4d_view_dot_scratch_bytes(V), dtype=torch.uint8, device=a.device)
+    rc = lib.t4d_view_dot(V, n, _ptr(a), _ptr(b), _ptr(out), _ptr(scratch),
+                          C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+    if rc != T4D_OK:
+        raise RuntimeError(f"t4d_view_dot failed (code {rc}): {_lib.last_error()}")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 # autograd glue
 # ------------------------------------------------------------------------------------------------------------
