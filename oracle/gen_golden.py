@@ -1,0 +1,169 @@
+"""
+TEST INFRASTRUCTURE.  Generates tests/golden/*.npz by IMPORTING THE REAL REFERENCE (/root/reference) in this
+container.  The reference cannot travel to the GPU box, so its outputs are committed as small data fixtures
+together with this script.  Nothing here is product code and no reference source text is stored in the fixtures —
+only seeded inputs and the numbers the reference functions returned.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/g1..g4,g6 (g5 is written by oracle/build_ref.py)
+
+G1  helpers.setup_camera          (helpers.py:63-88)   3 synthetic (K, w2c, w, h) -> the 12 Settings fields
+G2  helpers.params2rendervar      (helpers.py:91-100)  seeded P=64 parameter dict -> rasterizer kwargs
+G3  helpers.l1_loss_v1 + external.calc_ssim (helpers.py:115-116, external.py:73-116) on seeded 3x64x64 pairs,
+    with the gradient of 0.8*L1 + 0.2*(1-SSIM) w.r.t. the rendered image (train.py:315)
+G4  helpers.eval_sh               (helpers.py:865-922) degrees 0..3 on seeded [P=32,3,16] coefficients
+G6  SELF-GENERATED (not reference-derived): forward outputs + all gradients of oracle/torch_oracle.py (float64)
+    on a 64x64 / P=200 scene; pins the oracle against accidental edits.
+The rasterizer itself has no reference-derived golden vectors: its source is absent from /root/reference
+ — parity unpinned.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def import_reference_helpers():
+    from typing import NamedTuple
+
+    class Camera(NamedTuple):
+        image_height: int
+        image_width: int
+        tanfovx: float
+        tanfovy: float
+        bg: torch.Tensor
+        scale_modifier: float
+        viewmatrix: torch.Tensor
+        projmatrix: torch.Tensor
+        sh_degree: int
+        campos: torch.Tensor
+        prefiltered: bool
+        debug: bool
+
+    stubs = ["imageio", "open3d", "pywavefront", "nvdiffrast", "nvdiffrast.torch", "torchvision", "torchvision.utils",
+             "skimage", "skimage.io", "trimesh", "face3d", "diff_gaussian_rasterization", "cv2", "pymesh"]
+    for name in stubs:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.utils"].save_image = lambda *a, **k: None
+    sys.modules["skimage"].io = sys.modules["skimage.io"]
+    sys.modules["face3d"].mesh = types.ModuleType("face3d.mesh")
+    sys.modules["nvdiffrast"].torch = sys.modules["nvdiffrast.torch"]
+    sys.modules["diff_gaussian_rasterization"].GaussianRasterizer = object
+    sys.modules["diff_gaussian_rasterization"].GaussianRasterizationSettings = Camera
+    # no GPU in this container: .cuda() / device="cuda" become no-ops
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    _tensor, _zeros_like = torch.tensor, torch.zeros_like
+
+    def tensor(*a, **k):
+        k.pop("device", None)
+        return _tensor(*a, **k)
+
+    def zeros_like(*a, **k):
+        k.pop("device", None)
+        return _zeros_like(*a, **k)
+    torch.tensor, torch.zeros_like = tensor, zeros_like
+    sys.path.insert(0, REF)
+    import external  # noqa
+    import helpers  # noqa
+    return helpers, external
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    helpers, external = import_reference_helpers()
+    rng = np.random.default_rng(0)
+
+    # ---- G1 -------------------------------------------------------------------------------------------------
+    g1 = {}
+    cases = [(375, 512, 820.0, 815.0, 190.0, 250.0), (512, 512, 1344.0, 1344.0, 256.0, 256.0), (750, 1024, 1650.5, 1640.25, 370.0, 515.5)]
+    for i, (w, h, fx, fy, cx, cy) in enumerate(cases):
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+        a = rng.normal(size=3)
+        a /= np.linalg.norm(a)
+        th = rng.uniform(0.2, 1.2)
+        Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        w2c = np.eye(4)
+        w2c[:3, :3] = R
+        w2c[:3, 3] = rng.normal(size=3) * 0.3 + np.array([0, 0, 0.9])
+        cam = helpers.setup_camera(None, w, h, K, w2c, near=0.01, far=100)
+        g1[f"K{i}"] = K
+        g1[f"w2c{i}"] = w2c
+        g1[f"wh{i}"] = np.array([w, h])
+        g1[f"scalars{i}"] = np.array([cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, cam.scale_modifier,
+                                      cam.sh_degree, int(cam.prefiltered), int(cam.debug)], dtype=np.float64)
+        g1[f"bg{i}"] = cam.bg.numpy()
+        g1[f"viewmatrix{i}"] = cam.viewmatrix.numpy()
+        g1[f"projmatrix{i}"] = cam.projmatrix.numpy()
+        g1[f"campos{i}"] = cam.campos.numpy()
+    np.savez(os.path.join(OUT, "g1_setup_camera.npz"), **g1)
+
+    # ---- G2 -------------------------------------------------------------------------------------------------
+    P = 64
+    params = {"means3D": rng.normal(size=(P, 3)) * 0.1, "rgb_colors": rng.uniform(size=(P, 3)),
+              "unnorm_rotations": rng.normal(size=(P, 4)), "logit_opacities": rng.normal(size=(P, 1)) * 3,
+              "log_scales": rng.normal(size=(P, 3)) - 5}
+    params_t = {k: torch.tensor(v).float() for k, v in params.items()}
+    rv = helpers.params2rendervar(params_t)
+    g2 = {f"in_{k}": v.numpy() for k, v in params_t.items()}
+    g2.update({f"out_{k}": v.detach().numpy() for k, v in rv.items()})
+    np.savez(os.path.join(OUT, "g2_params2rendervar.npz"), **g2)
+
+    # ---- G3 -------------------------------------------------------------------------------------------------
+    g3 = {}
+    for i in range(3):
+        im = torch.tensor(rng.uniform(size=(3, 64, 64))).float().requires_grad_(True)
+        gt = torch.tensor(np.clip(im.detach().numpy() + rng.normal(size=(3, 64, 64)) * 0.1, 0, 1)).float()
+        l1 = helpers.l1_loss_v1(im, gt)
+        ssim = external.calc_ssim(im, gt)
+        loss = 0.8 * l1 + 0.2 * (1.0 - ssim)
+        (grad,) = torch.autograd.grad(loss, im)
+        g3[f"im{i}"] = im.detach().numpy()
+        g3[f"gt{i}"] = gt.numpy()
+        g3[f"l1_{i}"] = np.float64(l1.item())
+        g3[f"ssim_{i}"] = np.float64(ssim.item())
+        g3[f"loss_{i}"] = np.float64(loss.item())
+        g3[f"grad{i}"] = grad.numpy()
+    np.savez(os.path.join(OUT, "g3_photometric.npz"), **g3)
+
+    # ---- G4 -------------------------------------------------------------------------------------------------
+    sh = torch.tensor(rng.normal(size=(32, 3, 16))).float()
+    d = rng.normal(size=(32, 3))
+    d = torch.tensor(d / np.linalg.norm(d, axis=1, keepdims=True)).float()
+    g4 = {"sh": sh.numpy(), "dirs": d.numpy()}
+    for deg in range(4):
+        g4[f"eval_deg{deg}"] = helpers.eval_sh(deg, sh, d).numpy()
+    g4["C0"] = np.float64(helpers.C0)
+    g4["C1"] = np.float64(helpers.C1)
+    g4["C2"] = np.array(helpers.C2)
+    g4["C3"] = np.array(helpers.C3)
+    g4["RGB2SH_half"] = helpers.RGB2SH(torch.tensor([0.0, 0.5, 1.0])).numpy()
+    np.savez(os.path.join(OUT, "g4_eval_sh.npz"), **g4)
+
+    # ---- G6 (self-generated) --------------------------------------------------------------------------------
+    from oracle import torch_oracle as TO
+    from topo4d_amd import boundary, scene
+    p = scene.make_gaussians(10, 20, opacity="B", seed=6)
+    rvv = {k: v.detach() for k, v in boundary.params2rendervar(p).items()}
+    cam = scene.camera_rig(64, 64, n_views=3)[1]
+    dc, dd, da = scene.output_cotangents(1, 64, 64, seed=7, depth_alpha=True)
+    outs, grads = TO.rasterize_with_grads(TO.View(*cam), rvv["means3D"], rvv["opacities"], rvv["scales"], rvv["rotations"],
+                                          colors_precomp=rvv["colors_precomp"], dL_dcolor=dc[0], dL_ddepth=dd[0],
+                                          dL_dalpha=da[0])
+    g6 = {"color": outs["color"].numpy(), "depth": outs["depth"].numpy(), "alpha": outs["alpha"].numpy(),
+          "radii": outs["radii"].numpy(), "n_contrib": outs["n_contrib"].numpy()}
+    g6.update({f"grad_{k}": v.numpy() for k, v in grads.items()})
+    np.savez_compressed(os.path.join(OUT, "g6_self_oracle_f64.npz"), **g6)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""CPU, world_size 2 over gloo: the multi-GPU driver's sharding and loss gather (the only collective on the path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from topo4d_amd import dist as t4d_dist
+
+
+def test_shard_units_partition():
+    for n, w in ((24, 8), (24, 5), (64, 8), (3, 8), (1536, 8)):
+        seen = []
+        for r in range(w):
+            s = t4d_dist.shard_units(n, r, w)
+            assert s == list(range(r, n, w))
+            seen += s
+        assert sorted(seen) == list(range(n))
+        assert t4d_dist.shard_sizes(n, w) == [len(t4d_dist.shard_units(n, r, w)) for r in range(w)]
+    assert t4d_dist.shard_sizes(24, 8) == [3] * 8
+    with pytest.raises(ValueError):
+        t4d_dist.shard_units(24, 8, 8)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_units):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = t4d_dist.shard_units(n_units, rank, world)
+        # the "loss" of unit u is a known function of u, so every rank can check the gathered vector
+        local = torch.tensor([float(u) * 0.5 + 1.0 for u in mine])
+        allv = t4d_dist.gather_losses(local, n_units=n_units)
+        assert torch.equal(allv, torch.arange(n_units).float() * 0.5 + 1.0), (rank, allv)
+        if n_units % world == 0:
+            allv2 = t4d_dist.gather_losses(local)                  # equal-shard fast path
+            assert torch.equal(allv2, allv)
+        g = [torch.full((5, 3), float(rank + 1)), torch.full((7,), float(rank + 1))]
+        t4d_dist.all_reduce_grads(g)
+        tot = float(sum(range(1, world + 1)))
+        assert torch.all(g[0] == tot) and torch.all(g[1] == tot)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_units", [24, 7])
+def test_gather_losses_world2_gloo(n_units):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_units), nprocs=2, join=True)
+
+
+def test_single_process_gather_is_identity():
+    x = torch.arange(5.0)
+    assert t4d_dist.gather_losses(x) is x

@@ -1,0 +1,107 @@
+"""CPU: host-side logic of the drop-in module — API surface, argument validation (mirrors upstream's messages),
+view-record packing, capacity policy, and the "no CPU fallback" contract."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import topo4d_amd
+from topo4d_amd import _lib, boundary, rasterizer, scene
+
+
+def _cam():
+    return scene.camera_rig(64, 64, n_views=3)[1]
+
+
+def test_drop_in_module_surface():
+    import diff_gaussian_rasterization as dgr
+    assert dgr.GaussianRasterizer is topo4d_amd.GaussianRasterizer
+    assert dgr.GaussianRasterizationSettings is topo4d_amd.GaussianRasterizationSettings
+    s = _cam()
+    assert len(s) == 12
+    r = dgr.GaussianRasterizer(raster_settings=s)            # keyword used at train.py:307
+    assert isinstance(r, torch.nn.Module) and r.raster_settings is s
+    assert hasattr(r, "markVisible")
+    import inspect
+    assert list(inspect.signature(r.forward).parameters) == ["means3D", "means2D", "opacities", "shs", "colors_precomp",
+                                                              "scales", "rotations", "cov3D_precomp"]
+
+
+def test_argument_validation_messages_match_upstream():
+    r = topo4d_amd.GaussianRasterizer(_cam())
+    P = 4
+    m = torch.zeros(P, 3); o = torch.ones(P, 1); s = torch.ones(P, 3); q = torch.ones(P, 4); c = torch.ones(P, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, o, scales=s, rotations=q)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, o, shs=torch.ones(P, 1, 3), colors_precomp=c, scales=s, rotations=q)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, o, colors_precomp=c, scales=s)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, o, colors_precomp=c, scales=s, rotations=q, cov3D_precomp=torch.ones(P, 6))
+
+
+def test_no_cpu_fallback():
+    r = topo4d_amd.GaussianRasterizer(_cam())
+    P = 4
+    m = torch.zeros(P, 3); o = torch.ones(P, 1); s = torch.ones(P, 3); q = torch.ones(P, 4); c = torch.ones(P, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(m, m, o, colors_precomp=c, scales=s, rotations=q)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r.markVisible(m)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        topo4d_amd.ViewBatch(torch.zeros(1, 40), 64, 64)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtopo4d_raster.so")
+    with pytest.raises(_lib.ExtensionMissing, match="not built"):
+        _lib.load()
+
+
+def test_pack_views_layout_and_cache():
+    cams = scene.camera_rig(64, 48, n_views=3)
+    rec = rasterizer.pack_views(cams, torch.device("cpu"))
+    assert rec.shape == (3, _lib.T4D_VIEW_FLOATS) and rec.dtype == torch.float32
+    for i, c in enumerate(cams):
+        np.testing.assert_array_equal(rec[i, :16].numpy(), c.viewmatrix.reshape(-1).numpy())
+        np.testing.assert_array_equal(rec[i, 16:32].numpy(), c.projmatrix.reshape(-1).numpy())
+        np.testing.assert_array_equal(rec[i, 32:35].numpy(), c.campos.numpy())
+        np.testing.assert_array_equal(rec[i, 35:38].numpy(), c.bg.numpy())
+        assert rec[i, 38].item() == np.float32(c.tanfovx) and rec[i, 39].item() == np.float32(c.tanfovy)
+    # element (row r, col c) of the mathematical world->view matrix sits at [c*4+r] (helpers.py:67 transposes)
+    w2c = cams[0].viewmatrix[0].T
+    assert rec[0, 1 * 4 + 2].item() == w2c[2, 1].item()
+    rec2 = rasterizer.pack_views(cams, torch.device("cpu"))
+    assert rec2[0].data_ptr() != 0 and torch.equal(rec, rec2)
+    cams[0].viewmatrix.mul_(1.0)                       # in-place edit bumps the version -> cache entry is rebuilt
+    assert torch.equal(rasterizer.pack_views(cams, torch.device("cpu")), rec)
+    with pytest.raises(ValueError):
+        rasterizer._check_common([cams[0], cams[1]._replace(image_height=32)])
+
+
+def test_capacity_policy():
+    assert rasterizer._initial_capacity(10) == 16384 and rasterizer._initial_capacity(30000) == 240000
+    c = rasterizer._round_capacity(74000)
+    assert c >= 1.5 * 74000 and c % 1024 == 0
+    with pytest.raises(ValueError):
+        topo4d_amd.set_sync_mode("sometimes")
+    topo4d_amd.set_sync_mode("lazy"); assert topo4d_amd.get_sync_mode() == "lazy"
+    topo4d_amd.set_sync_mode("checked")
+
+
+def test_scene_generator_is_seeded_and_matches_reference_recipe():
+    a = scene.make_gaussians(20, 30, opacity="A", seed=0)
+    b = scene.make_gaussians(20, 30, opacity="A", seed=0)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert a["means3D"].shape == (600, 3)
+    assert torch.all(torch.sigmoid(a["logit_opacities"]) == 1.0)           # train.py:142: logit 1000
+    assert torch.allclose(a["log_scales"][:, 0], a["log_scales"][:, 1])    # isotropic (train.py:143)
+    cams = scene.camera_rig(512, 512, 24)
+    assert len(cams) == 24 and cams[0].viewmatrix.shape == (1, 4, 4)
+    rv = boundary.params2rendervar(a)
+    assert torch.allclose(rv["rotations"].norm(dim=1), torch.ones(600), atol=1e-6)
+    assert scene.CONFIGS["C2"] == dict(n_lat=150, n_lon=200, H=512, W=512, n_views=24, sh_degree=None)

@@ -1,0 +1,50 @@
+"""
+Photometric loss on the rendered image — the consumer of the rasterizer output whose gradient is the rasterizer's
+backward input (reference train.py:310,315: per-camera affine, then 0.8*L1 + 0.2*(1-SSIM)).
+
+`photometric_loss_torch` restates helpers.py:115-116 (`l1_loss_v1`) and external.py:73-116 (`calc_ssim`: 11x11
+Gaussian window, sigma 1.5, zero padding, c1 = 0.01^2, c2 = 0.03^2, mean over all pixels) with plain torch ops;
+it is pinned by tests/golden/g3_photometric.npz (values captured from the real reference functions).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+WINDOW = 11
+SIGMA = 1.5
+C1 = 0.01 ** 2
+C2 = 0.03 ** 2
+
+
+def gaussian_window_1d(dtype=torch.float32, device="cpu") -> torch.Tensor:
+    g = torch.tensor([math.exp(-(x - WINDOW // 2) ** 2 / float(2 * SIGMA ** 2)) for x in range(WINDOW)], dtype=dtype)
+    return (g / g.sum()).to(device)
+
+
+def ssim_torch(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
+    """external.py:85-116 with size_average=True.  img: [C,H,W] or [N,C,H,W]."""
+    squeeze = img1.dim() == 3
+    if squeeze:
+        img1, img2 = img1[None], img2[None]
+    ch = img1.shape[1]
+    w1 = gaussian_window_1d(img1.dtype, img1.device)
+    w2 = (w1[:, None] @ w1[None, :])[None, None].expand(ch, 1, WINDOW, WINDOW).contiguous()
+    pad = WINDOW // 2
+    conv = lambda x: F.conv2d(x, w2, padding=pad, groups=ch)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = conv(img1 * img1) - mu1_sq
+    s2 = conv(img2 * img2) - mu2_sq
+    s12 = conv(img1 * img2) - mu1_mu2
+    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean()
+
+
+def photometric_loss_torch(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tensor = None, cam_c: torch.Tensor = None):
+    """train.py:310,315: im' = exp(cam_m)[:,None,None]*im + cam_c[:,None,None]; 0.8*mean|im'-gt| + 0.2*(1-SSIM)."""
+    if cam_m is not None:
+        im = torch.exp(cam_m)[:, None, None] * im + cam_c[:, None, None]
+    return 0.8 * torch.abs(im - gt).mean() + 0.2 * (1.0 - ssim_torch(im, gt))
