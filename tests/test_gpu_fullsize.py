@@ -1,0 +1,194 @@
+"""
+GPU: the drop-in module end to end, the capacity/overflow policy, and BASELINE config 2 at FULL size
+(24 views x 512x512, P = 30,000) through size-independent properties plus a sampled comparison with the C oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.test_gpu_parity import check_grads, check_outputs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_drop_in_module_autograd_through_topo4d_activations():
+    """Renderer(raster_settings=cam)(**params2rendervar(params)) + the reference photometric loss, gradients on the
+    LEAF Parameters (train.py:303-315,667) vs float64 autograd through the same activations on the CPU oracle."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from oracle import torch_oracle as TO
+    from topo4d_amd import boundary, loss, scene
+    H = W = 64
+    p_cpu = scene.make_gaussians(12, 20, opacity="B", seed=3)
+    cams_cpu = scene.camera_rig(H, W, n_views=3)
+    g = torch.Generator().manual_seed(0)
+    p_cpu["log_scales"] = p_cpu["log_scales"] + torch.randn(240, 3, generator=g) * 0.3   # anisotropic: rotations matter
+    gt = torch.rand(3, H, W, generator=g)
+    cam_m, cam_c = torch.randn(3, generator=g) * 0.1, torch.randn(3, generator=g) * 0.05
+
+    params = {k: torch.nn.Parameter(v.cuda()) for k, v in p_cpu.items()}
+    cam = util.to_device(cams_cpu, "cuda")[1]
+    rv = boundary.params2rendervar(params)
+    rv["means2D"].retain_grad()
+    im, radius, depth, alpha = Renderer(raster_settings=cam)(**rv)
+    assert im.shape == (3, H, W) and depth.shape == (1, H, W) and alpha.shape == (1, H, W)
+    assert radius.shape == (240,) and radius.dtype == torch.int32
+    l = loss.photometric_loss_torch(im, gt.cuda(), cam_m.cuda(), cam_c.cuda())
+    l.backward()
+    seen = radius > 0                                                     # train.py:373-375 usage
+    assert seen.any() and torch.max(radius[seen], torch.zeros_like(radius[seen]).float()).dtype == torch.float32
+
+    pd = {k: v.double().clone().requires_grad_(True) for k, v in p_cpu.items()}
+    rvd = boundary.params2rendervar(pd)
+    view = TO.View(*cams_cpu[1])
+    m2 = torch.zeros(240, 3, dtype=torch.float64, requires_grad=True)
+    c, _, _, _ = TO.rasterize(view, rvd["means3D"], m2, rvd["opacities"], None, rvd["colors_precomp"], rvd["scales"],
+                              rvd["rotations"], None, dtype=torch.float64)
+    lref = loss.photometric_loss_torch(c, gt.double(), cam_m.double(), cam_c.double())
+    lref.backward()
+    assert abs(l.item() - lref.item()) < 1e-5
+    leaf = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
+    floor = 1e-6 * max(float(pd[k].grad.abs().max()) for k in leaf)
+    for k in leaf:
+        a = params[k].grad.cpu().double().numpy()
+        b = pd[k].grad.numpy()
+        assert np.abs(a - b).max() <= 3e-4 * np.abs(b).max() + floor, (k, np.abs(a - b).max(), np.abs(b).max())
+    a = rv["means2D"].grad.cpu().double().numpy()
+    assert np.abs(a - m2.grad.numpy()).max() <= 3e-4 * np.abs(m2.grad.numpy()).max() + 1e-9
+    assert np.abs(a[:, 2]).max() == 0
+
+
+def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypatch):
+    import topo4d_amd
+    from topo4d_amd import rasterizer, scene
+    H = W = 96
+    rv, cams = util.make_scene(20, 32, H, W, 3, opacity="B", seed=4)
+    dc, _, _ = scene.output_cotangents(3, H, W, seed=5)
+    ref, gref, _ = util.hip_render(cams, rv, dc)
+    key = (torch.device("cuda").index or 0, 640, H, W)
+    # (a) checked: start far too small -> T4D_ERR_PAIR_OVERFLOW -> retried with a larger arena, same results
+    monkeypatch.setattr(rasterizer, "_initial_capacity", lambda P: 256)
+    rasterizer._CAPACITY.clear()
+    out, g, batch = util.hip_render(cams, rv, dc)
+    assert batch.prob.pair_capacity > 256 and batch.last_status.overflow == 0
+    for k in ref:
+        np.testing.assert_array_equal(out[k], ref[k])
+    for k in gref:
+        if gref[k] is not None:
+            np.testing.assert_array_equal(g[k], gref[k])
+    # (b) lazy with a wrong learned capacity: lists are truncated, nothing is written out of bounds, status says so
+    rasterizer._CAPACITY[(0, 640, H, W)] = 512
+    rasterizer._CAPACITY[key] = 512
+    topo4d_amd.set_sync_mode("lazy")
+    try:
+        out2, g2, batch2 = util.hip_render(cams, rv, dc)
+        st = batch2.fetch_status()
+        assert st.overflow == 1 and st.max_pairs_per_view > 512
+        assert np.isfinite(out2["color"]).all()
+    finally:
+        topo4d_amd.set_sync_mode("checked")
+        rasterizer._CAPACITY.clear()
+
+
+def test_view_dot_and_mark_visible():
+    from topo4d_amd.rasterizer import view_dot
+    import topo4d_amd
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(5, 3, 37, 53, generator=g).cuda()
+    b = torch.randn(5, 3, 37, 53, generator=g).cuda()
+    ref = (a.double() * b.double()).sum(dim=(1, 2, 3))
+    out = view_dot(a, b)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-3)
+    a4 = torch.randn(3, 3, 64, 64, generator=g).cuda(); b4 = torch.randn(3, 3, 64, 64, generator=g).cuda()
+    assert torch.allclose(view_dot(a4, b4).double(), (a4.double() * b4.double()).sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.equal(view_dot(a4, b4), view_dot(a4, b4))
+    rv, cams = util.make_scene(6, 10, 32, 32, 1, seed=1)
+    cam = util.to_device(cams, "cuda")[0]
+    pts = torch.cat([rv["means3D"], rv["means3D"] + torch.tensor([0, 0, 50.0])]).cuda()
+    vis = topo4d_amd.GaussianRasterizer(cam).markVisible(pts)
+    assert vis[:60].all() and not vis[60:].any()
+
+
+@pytest.fixture(scope="module")
+def c2():
+    """BASELINE config 2, both output cotangents; rendered once for the tests below."""
+    from topo4d_amd import scene
+    cfg = scene.CONFIGS["C2"]
+    rv, cams = util.make_scene(cfg["n_lat"], cfg["n_lon"], cfg["H"], cfg["W"], cfg["n_views"], opacity="A", seed=0)
+    dc, dd, da = scene.output_cotangents(cfg["n_views"], cfg["H"], cfg["W"], seed=0, depth_alpha=True)
+    out, g, batch = util.hip_render(cams, rv, dc, dd, da)
+    return dict(rv=rv, cams=cams, dc=dc, dd=dd, da=da, out=out, g=g, batch=batch, st=util.decode_state(batch))
+
+
+def test_c2_full_size_binning_invariants(c2):
+    st = c2["st"]
+    assert st["status"][0] == 0
+    V = 24
+    np.testing.assert_array_equal(st["tile_count"].sum(axis=1), st["view_total"])
+    radii = c2["out"]["radii"]
+    assert (radii >= 0).all() and (radii > 0).sum() == 24 * 30000      # the whole head is inside every frustum
+    for v in (0, 7, 23):
+        offs, cnts = st["tile_off"][v], st["tile_count"][v]
+        # bins tile the arena without gaps or overlap
+        order = np.argsort(offs, kind="stable")
+        nz = order[cnts[order] > 0]
+        assert (offs[nz][1:] == offs[nz][:-1] + cnts[nz][:-1]).all()
+        keys = st["keys"][v]
+        seen = np.zeros(30000, np.int64)
+        for t in np.nonzero(cnts)[0]:
+            k = keys[offs[t]: offs[t] + cnts[t]]
+            assert (k[1:] > k[:-1]).all(), "per-tile list strictly ascending in (depth bits, index)"
+            idx = (k & np.uint64(0xffffffff)).astype(np.int64)
+            dep = (k >> np.uint64(32)).astype(np.uint32).view(np.float32)
+            np.testing.assert_array_equal(dep, st["depth"][v][idx])
+            seen[idx] += 1
+        # every Gaussian appears once per tile of its 3-sigma rectangle
+        xy, r = st["xy"][v], radii[v]
+        x0 = np.clip(np.trunc((xy[:, 0] - r) / 16), 0, 32); x1 = np.clip(np.trunc((xy[:, 0] + r + 15) / 16), 0, 32)
+        y0 = np.clip(np.trunc((xy[:, 1] - r) / 16), 0, 32); y1 = np.clip(np.trunc((xy[:, 1] + r + 15) / 16), 0, 32)
+        np.testing.assert_array_equal(seen, ((x1 - x0) * (y1 - y0)).astype(np.int64))
+
+
+def test_c2_full_size_image_identities(c2):
+    out, st = c2["out"], c2["st"]
+    # alpha = sum_i alpha_i T_i = 1 - prod(1 - alpha_i) = 1 - final_T
+    assert np.abs(out["alpha"][:, 0] + st["final_T"] - 1.0).max() < 5e-6
+    assert (st["final_T"] >= 1e-4 * 0.999).all() and (st["final_T"] <= 1.0).all()
+    assert (out["alpha"] >= 0).all() and (out["depth"] >= 0).all()
+    # background enters as T_final * bg: render again with bg = 1 and compare
+    cams1 = [c._replace(bg=torch.ones(3)) for c in c2["cams"][:4]]
+    out1, _, _ = util.hip_render(cams1, c2["rv"])
+    np.testing.assert_allclose(out1["color"] - out["color"][:4], np.repeat(st["final_T"][:4, None], 3, axis=1), rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(out1["alpha"], out["alpha"][:4])
+
+
+def test_c2_full_size_gradient_identities(c2):
+    g, out, st = c2["g"], c2["out"], c2["st"]
+    # (a) the backward is linear in the cotangents: doubling them doubles every gradient bit for bit
+    _, g2, _ = util.hip_render(c2["cams"], c2["rv"], 2 * c2["dc"], 2 * c2["dd"], 2 * c2["da"])
+    for k in g:
+        if g[k] is not None:
+            np.testing.assert_array_equal(g2[k], 2 * g[k])
+    # (b) checksum of checksums linking forward and backward: C = sum_g w_g c_g + T bg  =>
+    #     sum_g c_g . dL/dc_g = sum_pix dL/dC . (C - T bg)          (bg = 0 here)
+    _, gc, _ = util.hip_render(c2["cams"], c2["rv"], c2["dc"])
+    rgb = c2["rv"]["colors_precomp"].numpy().astype(np.float64)
+    lhs = (gc["colors_precomp"].astype(np.float64) * rgb[None]).sum(axis=(1, 2))
+    rhs = (c2["dc"].numpy().astype(np.float64) * out["color"]).sum(axis=(1, 2, 3))
+    np.testing.assert_allclose(lhs, rhs, rtol=2e-4, atol=1e-9)
+    # (c) screen-space gradient has no z component; culled Gaussians would have exactly zero gradient
+    assert np.abs(g["means2D"][..., 2]).max() == 0
+    for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp"):
+        assert np.isfinite(g[k]).all()
+
+
+def test_c2_full_size_sampled_views_against_c_oracle(c2):
+    for v in (0, 13):
+        r, gref = util.c_oracle_render(c2["cams"][v], c2["rv"], c2["dc"][v], c2["dd"][v], c2["da"][v])
+        np.testing.assert_array_equal(c2["out"]["radii"][v], r.radii)
+        assert int(c2["st"]["view_total"][v]) == r.num_rendered
+        os_ = r.state()
+        np.testing.assert_array_equal(c2["st"]["tile_count"][v], os_["ranges"][:, 1] - os_["ranges"][:, 0])
+        assert (c2["st"]["n_contrib"][v] == os_["n_contrib"]).mean() > 1 - 2e-4
+        check_outputs(c2["out"], r.color, r.depth, r.alpha, v)
+        check_grads(c2["g"], gref, v)
