@@ -793,13 +793,17 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
         if (b + tid < n) {
             const unsigned long long key = keys[b + tid];
             const uint32_t g = (uint32_t)key;
-            const float2 p = xy[g];
-            const float4 c = co[g];
-            s_xy[tid] = p;
-            s_q[tid] = scale_conic(c);
-            s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
-                                    __uint_as_float((uint32_t)(key >> 32)));
-            touch = block_touch_mask(p, cutoff_radius2(c), tx, ty);
+            // g >= P only happens in lazy mode after an arena overflow (slots of dropped pairs hold stale bytes):
+            // such entries are ignored instead of being dereferenced
+            if (g < (uint32_t)kp.P) {
+                const float2 p = xy[g];
+                const float4 c = co[g];
+                s_xy[tid] = p;
+                s_q[tid] = scale_conic(c);
+                s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
+                                        __uint_as_float((uint32_t)(key >> 32)));
+                touch = block_touch_mask(p, cutoff_radius2(c), tx, ty);
+            }
         }
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -995,13 +999,15 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
         const bool live = lo < tile_max;      // workgroup-uniform
         // ---- stage ----
         uint32_t touch = 0;
-        if (tid < cnt) {
+        if (tid < cnt) s_pair[tid] = 0xffffffffu;
+        if (tid < cnt && (uint32_t)keys[lo + tid] < (uint32_t)kp.P) {     // stale entries after an overflow are skipped
             const unsigned long long key = keys[lo + tid];
             const uint32_t g = (uint32_t)key;
             const float2 p = xy[g];
             int x0, y0, x1, y1;
             tile_rect(p.x, p.y, radii[g], kp.gx, kp.gy, x0, y0, x1, y1);
-            s_pair[tid] = pair_off[g] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            const int local = (ty - y0) * (x1 - x0) + (tx - x0);
+            s_pair[tid] = (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) ? pair_off[g] + (uint32_t)local : 0xffffffffu;
             if (live) {
                 const float4 c = co[g];
                 s_xy[tid] = p;
