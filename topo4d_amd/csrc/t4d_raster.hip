@@ -929,6 +929,9 @@ __device__ __forceinline__ int red10_index(const int lane)
 // A.4 backward replay.  No global atomics: one kGP-float record per (Gaussian,tile) pair.
 // record: [0,1] d/d(ndc xy)  [2,3,4] d/d(conic A,B,C)  [5] d/d opacity  [6,7,8] d/d rgb  [9] d/d depth
 // ---------------------------------------------------------------------------------------------------------
+// DA = the caller supplied dL/ddepth and/or dL/dalpha.  Topo4D discards depth and alpha (train.py:307), so its backward
+// runs the DA = false instantiation, which carries neither the two extra suffix accumulators nor their products.
+template <bool DA>
 __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
 {
     __shared__ float2 s_xy[kBwdBatch + 1];
@@ -978,8 +981,8 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
         last_contributor = kp.n_contrib[(size_t)v * HW + pix];
         const float *dc = kp.dL_dcolor + (size_t)v * 3 * HW;
         dp0 = dc[pix]; dp1 = dc[HW + pix]; dp2 = dc[2 * HW + pix];
-        if (kp.dL_ddepth) ddep = kp.dL_ddepth[(size_t)v * HW + pix];
-        if (kp.dL_dalpha) dalp = kp.dL_dalpha[(size_t)v * HW + pix];
+        if (DA && kp.dL_ddepth) ddep = kp.dL_ddepth[(size_t)v * HW + pix];
+        if (DA && kp.dL_dalpha) dalp = kp.dL_dalpha[(size_t)v * HW + pix];
     }
     float T = T_final;
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
@@ -1079,11 +1082,13 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
                         ar2 = fmaf(last_alpha, lc2, oma * ar2); lc2 = cd.z;
                         dL_dalpha = (cd.x - ar0) * dp0 + (cd.y - ar1) * dp1 + (cd.z - ar2) * dp2;
                         r[6] = dchannel_dcolor * dp0; r[7] = dchannel_dcolor * dp1; r[8] = dchannel_dcolor * dp2;
-                        adr = fmaf(last_alpha, ldp, oma * adr); ldp = cd.w;
-                        dL_dalpha += (cd.w - adr) * ddep;
-                        r[9] = dchannel_dcolor * ddep;
-                        aar = fmaf(oma, aar, last_alpha);
-                        dL_dalpha += (1.f - aar) * dalp;
+                        if (DA) {
+                            adr = fmaf(last_alpha, ldp, oma * adr); ldp = cd.w;
+                            dL_dalpha += (cd.w - adr) * ddep;
+                            r[9] = dchannel_dcolor * ddep;
+                            aar = fmaf(oma, aar, last_alpha);
+                            dL_dalpha += (1.f - aar) * dalp;
+                        }
                         dL_dalpha *= T;
                         last_alpha = alpha;
                         dL_dalpha -= T_final * inv * bg_dot;
@@ -1608,7 +1613,10 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
 
     { ProfScope ps_(stream, K_RENDER_BWD);
-    hipLaunchKernelGGL(k_render_bwd, dim3(tile_grid(kp.T * p.n_views, 4)), dim3(kBlock), 0, stream, kp);
+    if (kp.dL_ddepth || kp.dL_dalpha)
+        hipLaunchKernelGGL(k_render_bwd<true>, dim3(tile_grid(kp.T * p.n_views, 4)), dim3(kBlock), 0, stream, kp);
+    else
+        hipLaunchKernelGGL(k_render_bwd<false>, dim3(tile_grid(kp.T * p.n_views, 4)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);

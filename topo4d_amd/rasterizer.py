@@ -327,6 +327,7 @@ class _RasterizeViews(torch.autograd.Function):
             means3D, opacities, none_if_empty(scales), none_if_empty(rotations), none_if_empty(colors_precomp),
             none_if_empty(sh), none_if_empty(cov3Ds_precomp))
         ctx.batch = batch
+        ctx.set_materialize_grads(False)     # unused depth/alpha outputs arrive as None -> cheaper backward kernel
         ctx.mark_non_differentiable(radii)
         ctx.shapes = (means3D.shape, means2D.shape if means2D is not None else None, opacities.shape)
         return color, radii, depth, alpha
@@ -334,6 +335,8 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         batch: ViewBatch = ctx.batch
+        if grad_color is None:
+            grad_color = torch.zeros(batch.V, 3, batch.H, batch.W, dtype=torch.float32, device=batch.device)
         g = batch.backward(grad_color, grad_depth, grad_alpha)
         red = (lambda t: None if t is None else t.sum(0)) if batch.V > 1 else \
               (lambda t: None if t is None else t[0])
