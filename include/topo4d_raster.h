@@ -143,6 +143,21 @@ size_t t4d_view_dot_scratch_bytes(int32_t n_views);
 int t4d_view_dot(int32_t n_views, int64_t n_per_view, const float *a, const float *b, float *out, void *scratch,
                  void *hip_stream);
 
+/* UV-space texture bake (BASELINE config 5): drop-in for the reference's CPU rasterizer
+ *     void _render_colors_core(float* image, float* vertices, int* triangles, float* colors, float* depth_buffer,
+ *                              int nver, int ntri, int h, int w, int c)        face3d/mesh/cython/mesh_core.h:63-69
+ * reached from helpers.py:953-960 (write_texture) via face3d/mesh/render.py:52-86 (render_colors).  Same argument
+ * meaning (all pointers are DEVICE pointers here): vertices [nver,3] in pixel space (x, y, depth), triangles [ntri,3]
+ * int32, colors [nver,c], image [h,w,c] in/out (zeros or a background), depth_buffer [h,w] in/out (the caller fills it
+ * with -999999 like render.py:72).  Results are bit-identical to the reference, including its border-ring dilation
+ * (mesh_core.cpp:211) and "first triangle wins on equal depth".  rows [row_begin,row_end) select a horizontal band of
+ * the image (multi-GPU: one band per rank); pass 0,h for everything.  pair_capacity bounds the (triangle, 16x16 tile)
+ * pairs; on T4D_ERR_PAIR_OVERFLOW *pairs_needed (host) holds the size to retry with.  Synchronises the stream once. */
+size_t t4d_texture_bake_scratch_bytes(int32_t h, int32_t w, int64_t pair_capacity);
+int t4d_texture_bake(const float *vertices, const int32_t *triangles, const float *colors, int32_t nver, int32_t ntri,
+                     int32_t h, int32_t w, int32_t c, int32_t row_begin, int32_t row_end, float *image, float *depth_buffer,
+                     void *scratch, size_t scratch_bytes, int64_t pair_capacity, int64_t *pairs_needed, void *hip_stream);
+
 /* Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on.  Between
  * t4d_profile_begin() and t4d_profile_end() every kernel launch of this library is bracketed by two events;
  * t4d_profile_end() synchronises them and returns, per kernel, the summed elapsed time and the launch count.

@@ -1,0 +1,57 @@
+"""CPU: the texture-bake oracle (oracle/texture_oracle.c) against the REAL reference code (oracle/_ref, built from
+/root/reference/face3d/mesh/cython/mesh_core.cpp where that tree exists) and against golden G5 (outputs of that
+real code, committed)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import texture_oracle as TX
+
+G = os.path.join(os.path.dirname(__file__), "golden", "g5_render_colors.npz")
+
+
+def uv_mesh(n, h, w, seed=0, with_depth=False):
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.linspace(0.01, 0.99, n), np.linspace(0.01, 0.99, n), indexing="xy")
+    uv = np.stack([u.ravel(), v.ravel()], 1) + rng.normal(0, 0.2 / n, size=(n * n, 2))
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c_, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c_], 1), np.stack([b, d, c_], 1)]).astype(np.int32)
+    rng.shuffle(tris)
+    z = rng.normal(0, 1, n * n) if with_depth else np.zeros(n * n)
+    verts = np.stack([uv[:, 0] * (w - 1), h - uv[:, 1] * (h - 1) - 1, z], 1).astype(np.float32)
+    colors = rng.uniform(0, 1, size=(n * n, 3)).astype(np.float32)
+    return verts, tris, colors
+
+
+def test_port_matches_golden_outputs_of_the_real_reference():
+    g = np.load(G)
+    h, w = (int(x) for x in g["hw"])
+    np.testing.assert_array_equal(TX.render_colors_port(g["verts"], g["tris"], g["colors"], h, w), g["image"])
+    np.testing.assert_array_equal(TX.render_colors_port(g["verts_z"], g["tris_z"], g["colors"], h, w), g["image_z"])
+    ring = np.ones((h, w), bool); ring[2:h - 2, 2:w - 2] = False
+    assert (g["image"][ring] < 0).any(), "fixture exercises the extrapolating border ring (mesh_core.cpp:211)"
+
+
+@pytest.mark.skipif(not TX.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("with_depth", [False, True])
+def test_port_is_bit_identical_to_the_real_reference(with_depth):
+    for n, h, w, seed in ((24, 96, 80, 1), (40, 128, 128, 2)):
+        verts, tris, colors = uv_mesh(n, h, w, seed, with_depth)
+        a, da = TX.render_colors_ref(verts, tris, colors, h, w, return_depth=True)
+        b, db = TX.render_colors_port(verts, tris, colors, h, w, return_depth=True)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(da, db)
+    bg = np.random.default_rng(3).uniform(size=(h, w, 3)).astype(np.float32)
+    np.testing.assert_array_equal(TX.render_colors_ref(verts, tris[:50], colors, h, w, BG=bg),
+                                  TX.render_colors_port(verts, tris[:50], colors, h, w, BG=bg))
+
+
+def test_process_uv_mirror():
+    from topo4d_amd import texture
+    uv = np.array([[0.0, 0.0], [1.0, 1.0], [0.25, 0.5]])
+    keep = uv.copy()
+    out = texture.process_uv(uv, 64, 32)
+    np.testing.assert_array_equal(uv, keep)
+    np.testing.assert_allclose(out, [[0, 63, 0], [31, 0, 0], [7.75, 31.5 - 0.0, 0]][:2] + [[7.75, 64 - 0.5 * 63 - 1, 0]])

@@ -1375,6 +1375,12 @@ int fail(int code, const char *fmt, const char *a = "")
     snprintf(g_err, sizeof(g_err), fmt, a);
     return code;
 }
+}  // namespace
+
+// shared with the other translation units of this library (hidden visibility: not part of the ABI)
+int t4d_internal_fail(int code, const char *fmt, const char *a) { return fail(code, fmt, a); }
+
+namespace {
 
 #define T4D_HIP(call)                                                                          \
     do {                                                                                       \
