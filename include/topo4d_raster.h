@@ -143,6 +143,16 @@ size_t t4d_view_dot_scratch_bytes(int32_t n_views);
 int t4d_view_dot(int32_t n_views, int64_t n_per_view, const float *a, const float *b, float *out, void *scratch,
                  void *hip_stream);
 
+/* Fused photometric loss of Topo4D's render loop, forward AND gradient in one call (train.py:310,315;
+ * helpers.py:115-116 l1_loss_v1; external.py:73-116 calc_ssim):
+ *     im' = exp(cam_m[v,c]) * im + cam_c[v,c];   loss[v] = 0.8*mean|im'-gt| + 0.2*(1 - mean SSIM_11x11(im', gt))
+ * im, gt, dL_dim: [V,3,H,W]; cam_m, cam_c, dL_dcam_m, dL_dcam_c: [V,3] (both NULL = no affine / no gradient wanted);
+ * view_weight [V] = dL/dloss[v] (NULL = 1).  dL_dim is exactly the dL_dcolor input of t4d_rasterize_backward. */
+size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int32_t W);
+int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *cam_m,
+                         const float *cam_c, const float *view_weight, float *loss, float *dL_dim, float *dL_dcam_m,
+                         float *dL_dcam_c, void *scratch, size_t scratch_bytes, void *hip_stream);
+
 /* UV-space texture bake (BASELINE config 5): drop-in for the reference's CPU rasterizer
  *     void _render_colors_core(float* image, float* vertices, int* triangles, float* colors, float* depth_buffer,
  *                              int nver, int ntri, int h, int w, int c)        face3d/mesh/cython/mesh_core.h:63-69

@@ -1,0 +1,82 @@
+"""GPU: fused photometric loss (t4d_photometric_loss) vs the torch restatement of the reference (topo4d_amd/loss.py,
+pinned by golden G3) and vs G3 itself.  Tolerance: loss 2e-6 absolute, gradients 2e-5 of their max."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from topo4d_amd import loss
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "g3_photometric.npz")
+
+
+def test_matches_reference_golden_g3():
+    g = np.load(G)
+    im = torch.tensor(np.stack([g[f"im{i}"] for i in range(3)])).cuda().requires_grad_(True)
+    gt = torch.tensor(np.stack([g[f"gt{i}"] for i in range(3)])).cuda()
+    l = loss.photometric_loss(im, gt)
+    l.sum().backward()
+    for i in range(3):
+        assert abs(l[i].item() - float(g[f"loss_{i}"])) < 2e-6
+        ref = g[f"grad{i}"]
+        assert np.abs(im.grad[i].cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 75, 100), (24, 512, 512)])
+def test_matches_torch_restatement_with_camera_affine(shape):
+    V, H, W = shape
+    g = torch.Generator().manual_seed(V * H)
+    im = torch.rand(V, 3, H, W, generator=g)
+    gt = (im + torch.randn(V, 3, H, W, generator=g) * 0.1).clamp(0, 1)
+    cm = torch.randn(V, 3, generator=g) * 0.1
+    cc = torch.randn(V, 3, generator=g) * 0.05
+    wv = torch.rand(V, generator=g) + 0.5
+    a = [t.cuda().requires_grad_(True) for t in (im, cm, cc)]
+    l = loss.photometric_loss(a[0], gt.cuda(), a[1], a[2])
+    (l * wv.cuda()).sum().backward()
+    if V <= 3:
+        dev, dt = "cpu", torch.float64
+    else:
+        dev, dt = "cuda", torch.float32          # full-size case: compare on the GPU against the torch ops
+    b = [t.to(dev, dt).requires_grad_(True) for t in (im, cm, cc)]
+    lref = torch.stack([loss.photometric_loss_torch(b[0][v], gt[v].to(dev, dt), b[1][v], b[2][v]) for v in range(V)])
+    (lref * wv.to(dev, dt)).sum().backward()
+    assert torch.allclose(l.double().cpu(), lref.double().cpu(), atol=3e-6, rtol=0)
+    l1_step = 2 * 0.8 * float(wv.max()) / (3 * H * W)        # |d/dx 0.8*mean|x-y|| jumps by this where x' == gt to the last bit
+    for x, y in zip(a, b):
+        gx, gy = x.grad.double().cpu(), y.grad.double().cpu()
+        err = (gx - gy).abs()
+        tol = 5e-5 * gy.abs().max() + 1e-12
+        if gx.dim() == 4:
+            # sign(x'-gt) is discontinuous: among ~2e7 fp32 values a handful tie to the last bit and may resolve differently
+            assert (err > tol).float().mean() <= 1e-6 and err.max() <= l1_step * 1.01
+        else:
+            assert err.max() <= tol + l1_step
+
+
+def test_feeds_the_rasterizer_backward():
+    """loss(render) end to end: fused loss -> dL/dcolor -> t4d_rasterize_backward, vs the torch loss on the same render."""
+    from tests import util
+    from topo4d_amd import rasterize_views
+    H = W = 96
+    rv, cams = util.make_scene(20, 32, H, W, 3, opacity="B", seed=2)
+    dcams = util.to_device(cams, "cuda")
+    g = torch.Generator().manual_seed(1)
+    gt = torch.rand(3, 3, H, W, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        leaves = {k: v.cuda().clone().requires_grad_(True) for k, v in rv.items() if k != "means2D"}
+        color, radii, depth, alpha = rasterize_views(dcams, leaves["means3D"], None, leaves["opacities"], None,
+                                                     leaves["colors_precomp"], leaves["scales"], leaves["rotations"])
+        if fused:
+            l = loss.photometric_loss(color, gt).sum()
+        else:
+            l = sum(loss.photometric_loss_torch(color[v], gt[v]) for v in range(3))
+        l.backward()
+        res.append((l.item(), {k: v.grad.clone() for k, v in leaves.items()}))
+    assert abs(res[0][0] - res[1][0]) < 1e-5
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max() + 1e-10, k

@@ -1,0 +1,256 @@
+// t4d_photometric.hip — fused photometric loss (forward + gradient) for Topo4D's render loop on MI355X
+// (SURVEY.md §8 row a13 / §8f rank 1).
+//
+// Restates reference train.py:310,315 with helpers.py:115-116 (`l1_loss_v1`) and external.py:73-116 (`calc_ssim`):
+//     im' = exp(cam_m[c]) * im + cam_c[c]
+//     loss_v = 0.8 * mean|im' - gt| + 0.2 * (1 - mean SSIM_11x11(im', gt))          (mean over the 3*H*W values of view v)
+// SSIM: depthwise 11x11 Gaussian window (sigma 1.5), zero padding, c1 = 0.01^2, c2 = 0.03^2.
+// The reference spends 5 conv2d launches forward and their autograd backward per iteration; here one launch set per
+// batch of V views produces the per-view losses AND dL/d(im) (the rasterizer's backward input) AND dL/d(cam_m, cam_c):
+//   k_photo_stats   per (view, channel, 16x16 tile): stage im', gt with a 5-px halo in LDS, separable 11-tap filter of
+//                   (x, y, x^2, y^2, xy), SSIM map + L1 term -> partial loss sums, and the three adjoint maps
+//                   D1 = g*dS/dmu1, D2 = g*dS/dE[x^2], D3 = g*dS/dE[xy]
+//   k_photo_grad    per tile: separable filter of D1, D2, D3 (the window is symmetric: adjoint = same filter),
+//                   dL/dx' = G*D1 + 2x'(G*D2) + y(G*D3) + L1 term; affine backward; partial sums for cam_m / cam_c
+//   k_photo_final   fixed-order sums of the partials (deterministic)
+// Pinned by tests against topo4d_amd/loss.py, itself pinned by golden G3 captured from the real reference functions.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/topo4d_raster.h"
+
+#define T4D_EXPORT extern "C" __attribute__((visibility("default")))
+int t4d_internal_fail(int code, const char *fmt, const char *a);
+
+namespace {
+
+constexpr int kT = 16;            // tile
+constexpr int kR = 5;             // window radius (11 taps)
+constexpr int kHalo = kT + 2 * kR;   // 26
+constexpr int kLd = kHalo + 1;    // LDS row stride (bank spread)
+constexpr int kBlock = 256;
+constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
+
+struct PhP {
+    int V, H, W, tx, ty;
+    const float *im, *gt, *cam_m, *cam_c, *weight;
+    float *loss, *dL_dim, *dL_dm, *dL_dc;
+    float *D;            // [3][V*3*H*W] adjoint maps
+    float *part_loss;    // [V*3*tiles][2]  (sum |x'-y|, sum S)
+    float *part_cam;     // [V*3*tiles][2]  (sum g'*(x'-c), sum g')
+    float win[11];
+};
+
+__device__ __forceinline__ float block_sum(float v, float *s_red)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_photo_stats(const PhP P)
+{
+    __shared__ float s_x[kHalo][kLd], s_y[kHalo][kLd];
+    __shared__ float s_h[5][kHalo][kT + 1];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int vc = blockIdx.z, v = vc / 3;
+    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    const size_t HW = (size_t)P.H * P.W;
+    const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
+    const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
+    for (int i = tid; i < kHalo * kHalo; i += kBlock) {
+        const int r = i / kHalo, c = i - r * kHalo;
+        const int yy = y0 + r - kR, xx = x0 + c - kR;
+        float a = 0.f, b = 0.f;                                  // zero padding (external.py:86 padding=5)
+        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+            a = em * im[(size_t)yy * P.W + xx] + cc;
+            b = gt[(size_t)yy * P.W + xx];
+        }
+        s_x[r][c] = a; s_y[r][c] = b;
+    }
+    __syncthreads();
+    for (int i = tid; i < kHalo * kT; i += kBlock) {             // horizontal pass
+        const int r = i / kT, c = i - r * kT;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float a = s_x[r][c + k], b = s_y[r][c + k], w = P.win[k];
+            sx += w * a; sy += w * b; sxx += w * (a * a); syy += w * (b * b); sxy += w * (a * b);
+        }
+        s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4, px = x0 + lx, py = y0 + ly;
+    float l1 = 0.f, ss = 0.f;
+    if (px < P.W && py < P.H) {
+        float mu1 = 0.f, mu2 = 0.f, a = 0.f, c = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {                           // vertical pass
+            const float w = P.win[k];
+            mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx];
+            a += w * s_h[2][ly + k][lx]; c += w * s_h[3][ly + k][lx]; b += w * s_h[4][ly + k][lx];
+        }
+        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s11 = a - mu1s, s22 = c - mu2s, s12 = b - mu12;
+        const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
+        const float inv = 1.f / (B1 * B2);
+        const float S = A1 * A2 * inv;
+        ss = S;
+        l1 = fabsf(s_x[ly + kR][lx + kR] - s_y[ly + kR][lx + kR]);
+        const float N = 3.f * (float)HW;
+        const float g = -0.2f * (P.weight ? P.weight[v] : 1.f) / N;          // dL/dS
+        // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
+        const float dS_dmu1 = (2.f * mu2 * (A2 - A1)) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
+        const float dS_da = -S / B2;
+        const float dS_db = 2.f * A1 * inv;
+        const size_t o = (size_t)vc * HW + (size_t)py * P.W + px, plane = (size_t)P.V * 3 * HW;
+        P.D[o] = g * dS_dmu1;
+        P.D[plane + o] = g * dS_da;
+        P.D[2 * plane + o] = g * dS_db;
+    }
+    const float tl1 = block_sum(l1, s_red);
+    const float tss = block_sum(ss, s_red);
+    if (tid == 0) {
+        const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
+        P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_photo_grad(const PhP P)
+{
+    __shared__ float s_d[3][kHalo][kLd];
+    __shared__ float s_h[3][kHalo][kT + 1];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int vc = blockIdx.z, v = vc / 3;
+    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    const size_t HW = (size_t)P.H * P.W, plane = (size_t)P.V * 3 * HW;
+    const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
+    for (int i = tid; i < kHalo * kHalo; i += kBlock) {
+        const int r = i / kHalo, c = i - r * kHalo;
+        const int yy = y0 + r - kR, xx = x0 + c - kR;
+        const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+        const size_t o = (size_t)vc * HW + (size_t)(in ? yy : 0) * P.W + (in ? xx : 0);
+#pragma unroll
+        for (int m = 0; m < 3; m++) s_d[m][r][c] = in ? P.D[m * plane + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < kHalo * kT; i += kBlock) {
+        const int r = i / kT, c = i - r * kT;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = P.win[k];
+            s0 += w * s_d[0][r][c + k]; s1 += w * s_d[1][r][c + k]; s2 += w * s_d[2][r][c + k];
+        }
+        s_h[0][r][c] = s0; s_h[1][r][c] = s1; s_h[2][r][c] = s2;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4, px = x0 + lx, py = y0 + ly;
+    float gm = 0.f, gc = 0.f;
+    if (px < P.W && py < P.H) {
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float w = P.win[k];
+            c0 += w * s_h[0][ly + k][lx]; c1 += w * s_h[1][ly + k][lx]; c2 += w * s_h[2][ly + k][lx];
+        }
+        const size_t o = (size_t)vc * HW + (size_t)py * P.W + px;
+        const float imv = P.im[o], y = P.gt[o];
+        const float x = em * imv + cc;
+        const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
+        const float d = x - y;
+        const float gl1 = 0.8f * wv / N * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        const float g = c0 + 2.f * x * c1 + y * c2 + gl1;         // dL/dx'
+        P.dL_dim[o] = em * g;
+        gm = g * (em * imv);                                      // d x'/d cam_m = exp(cam_m) * im
+        gc = g;
+    }
+    const float tgm = block_sum(gm, s_red);
+    const float tgc = block_sum(gc, s_red);
+    if (tid == 0) {
+        const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
+        P.part_cam[2 * t] = tgm; P.part_cam[2 * t + 1] = tgc;
+    }
+}
+
+// one workgroup per view: fixed-order sums of the per-tile partials
+__global__ __launch_bounds__(kBlock) void k_photo_final(const PhP P)
+{
+    __shared__ float s_red[4];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int tiles = P.tx * P.ty;
+    float l1 = 0.f, ss = 0.f;
+    for (int i = tid; i < 3 * tiles; i += kBlock) {
+        const size_t t = (size_t)v * 3 * tiles + i;
+        l1 += P.part_loss[2 * t]; ss += P.part_loss[2 * t + 1];
+    }
+    const float tl1 = block_sum(l1, s_red), tss = block_sum(ss, s_red);
+    const float N = 3.f * (float)P.H * (float)P.W;
+    if (tid == 0) P.loss[v] = 0.8f * (tl1 / N) + 0.2f * (1.f - tss / N);
+    if (P.dL_dm && P.dL_dc) {
+        for (int ch = 0; ch < 3; ch++) {
+            float gm = 0.f, gc = 0.f;
+            for (int i = tid; i < tiles; i += kBlock) {
+                const size_t t = ((size_t)v * 3 + ch) * tiles + i;
+                gm += P.part_cam[2 * t]; gc += P.part_cam[2 * t + 1];
+            }
+            const float tgm = block_sum(gm, s_red), tgc = block_sum(gc, s_red);
+            if (tid == 0) { P.dL_dm[v * 3 + ch] = tgm; P.dL_dc[v * 3 + ch] = tgc; }
+        }
+    }
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+T4D_EXPORT size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int32_t W)
+{
+    if (n_views < 1 || H < 1 || W < 1) return 0;
+    const size_t n = (size_t)n_views * 3 * H * W;
+    const size_t tiles = (size_t)((W + kT - 1) / kT) * ((H + kT - 1) / kT) * n_views * 3;
+    return align_up(3 * n * 4) + 2 * align_up(tiles * 8);
+}
+
+T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *cam_m,
+                                    const float *cam_c, const float *view_weight, float *loss, float *dL_dim, float *dL_dcam_m,
+                                    float *dL_dcam_c, void *scratch, size_t scratch_bytes, void *hip_stream)
+{
+    if (n_views < 1 || H < 1 || W < 1 || !im || !gt || !loss || !dL_dim || !scratch)
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: bad arguments%s", "");
+    if ((cam_m == nullptr) != (cam_c == nullptr) || (dL_dcam_m == nullptr) != (dL_dcam_c == nullptr))
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: cam_m/cam_c (and their gradients) come in pairs%s", "");
+    if (scratch_bytes < t4d_photometric_scratch_bytes(n_views, H, W))
+        return t4d_internal_fail(T4D_ERR_STATE_SIZE, "t4d_photometric_loss: scratch too small%s", "");
+    if ((size_t)n_views * 3 > 65535) return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: too many views%s", "");
+    PhP P;
+    memset(&P, 0, sizeof(P));
+    P.V = n_views; P.H = H; P.W = W;
+    P.tx = (W + kT - 1) / kT; P.ty = (H + kT - 1) / kT;
+    P.im = im; P.gt = gt; P.cam_m = cam_m; P.cam_c = cam_c; P.weight = view_weight;
+    P.loss = loss; P.dL_dim = dL_dim; P.dL_dm = dL_dcam_m; P.dL_dc = dL_dcam_c;
+    const size_t n = (size_t)n_views * 3 * H * W, tiles = (size_t)P.tx * P.ty * n_views * 3;
+    char *sc = (char *)scratch;
+    P.D = (float *)sc;
+    P.part_loss = (float *)(sc + align_up(3 * n * 4));
+    P.part_cam = (float *)(sc + align_up(3 * n * 4) + align_up(tiles * 8));
+    // the reference's window: exp(-(i-5)^2 / (2*1.5^2)) for i = 0..10, as float32, normalised in float32 (external.py:73-76)
+    float g[11], sum = 0.f;
+    for (int i = 0; i < 11; i++) { g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
+    for (int i = 0; i < 11; i++) P.win[i] = g[i] / sum;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const dim3 grid(P.tx, P.ty, n_views * 3);
+    hipLaunchKernelGGL(k_photo_stats, grid, dim3(kBlock), 0, stream, P);
+    hipLaunchKernelGGL(k_photo_grad, grid, dim3(kBlock), 0, stream, P);
+    hipLaunchKernelGGL(k_photo_final, dim3(n_views), dim3(kBlock), 0, stream, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_photometric_loss launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}

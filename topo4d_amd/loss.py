@@ -48,3 +48,49 @@ def photometric_loss_torch(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tens
     if cam_m is not None:
         im = torch.exp(cam_m)[:, None, None] * im + cam_c[:, None, None]
     return 0.8 * torch.abs(im - gt).mean() + 0.2 * (1.0 - ssim_torch(im, gt))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused HIP version (t4d_photometric_loss): forward + gradient in one launch set for a batch of views
+# ------------------------------------------------------------------------------------------------------------
+class _FusedPhotometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, gt, cam_m, cam_c):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        if not im.is_cuda:
+            raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+        im_c, gt_c = im.float().contiguous(), gt.float().contiguous()
+        V, _, H, W = im_c.shape
+        dev = im_c.device
+        loss = torch.empty(V, dtype=torch.float32, device=dev)
+        d_im = torch.empty_like(im_c)
+        have_cam = cam_m is not None
+        cm = cam_m.float().contiguous() if have_cam else None
+        cc = cam_c.float().contiguous() if have_cam else None
+        d_m = torch.empty(V, 3, dtype=torch.float32, device=dev) if have_cam else None
+        d_c = torch.empty(V, 3, dtype=torch.float32, device=dev) if have_cam else None
+        nbytes = lib.t4d_photometric_scratch_bytes(V, H, W)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = lib.t4d_photometric_loss(V, H, W, p(im_c), p(gt_c), p(cm), p(cc), None, p(loss), p(d_im), p(d_m), p(d_c),
+                                      p(scratch), nbytes, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"t4d_photometric_loss failed (code {rc}): {_lib.last_error()}")
+        ctx.save_for_backward(d_im, d_m, d_c)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        d_im, d_m, d_c = ctx.saved_tensors
+        g_im = d_im * go.view(-1, 1, 1, 1)
+        g_m = None if d_m is None else d_m * go.view(-1, 1)
+        g_c = None if d_c is None else d_c * go.view(-1, 1)
+        return g_im, None, g_m, g_c
+
+
+def photometric_loss(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tensor = None, cam_c: torch.Tensor = None) -> torch.Tensor:
+    """Per-view loss [V] for im, gt [V,3,H,W] (cam_m, cam_c [V,3] optional) — train.py:310,315 fused on the GPU.
+    Differentiable w.r.t. im, cam_m, cam_c."""
+    return _FusedPhotometric.apply(im, gt, cam_m, cam_c)
