@@ -34,7 +34,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-shared"] + sources() + ["-o", OUT]
+    extra = os.environ.get("T4D_CFLAGS", "").split()          # e.g. -DT4D_ABL=2 for the ablation builds of tools/ablate.sh
+    cmd = [hipcc] + FLAGS + extra + ["-shared"] + sources() + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -35,6 +35,13 @@
 
 namespace {
 
+// T4D_ABL (ablation builds, tools/ablate.sh; never defined in the shipped library):
+//   1 = backward: skip the cross-lane reduction + LDS slab write      2 = backward: skip the gradient arithmetic too
+//   3 = backward: skip the whole visit loop (staging + write-out only) 4 = forward: skip blending (alpha evaluation only)
+//   5 = forward: skip the whole visit loop
+#ifndef T4D_ABL
+#define T4D_ABL 0
+#endif
 constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave64)
 constexpr int kFwdBatch = 256;       // splats staged in LDS per round of the forward blend
 constexpr int kBwdBatch = 128;       // splats staged per round of the backward replay
@@ -816,7 +823,10 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
 #pragma unroll
         for (int c4 = 0; c4 < kFwdBatch / 64; c4++) m[c4] = uniform_u64(s_mask[wave][c4]);
         unsigned short *list = s_list[wave];
-        const int cnt = build_visit_list<kFwdBatch / 64, false>(m, list, lane, (unsigned short)kNull);
+        int cnt = build_visit_list<kFwdBatch / 64, false>(m, list, lane, (unsigned short)kNull);
+#if T4D_ABL == 5
+        cnt = 0;
+#endif
         for (int k = 0; k < cnt; k += 4) {
             const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
             const int j[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
@@ -831,6 +841,10 @@ __global__ __launch_bounds__(kBlock) void k_render_fwd(const KP kp)
                 valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
                 anyv = anyv || valid[u];
             }
+#if T4D_ABL == 4
+            if (alpha[0] + alpha[1] + alpha[2] + alpha[3] == 12345.f) C0 += 1.f;
+            continue;
+#endif
             if (!__any(anyv && !done)) continue;
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // blending is sequential in list order
@@ -927,7 +941,8 @@ __device__ __forceinline__ int red10_index(const int lane)
 
 // ---------------------------------------------------------------------------------------------------------
 // A.4 backward replay.  No global atomics: one kGP-float record per (Gaussian,tile) pair.
-// record: [0,1] d/d(ndc xy)  [2,3,4] d/d(conic A,B,C)  [5] d/d opacity  [6,7,8] d/d rgb  [9] d/d depth
+// record (raw sums over the tile's pixels, e = G * dL/dalpha, d = splat centre - pixel):
+//   [0] sum e   [1,2] sum e*d   [3,4,5] sum e*dx*dx, e*dx*dy, e*dy*dy   [6,7,8] sum alpha*T*dL/dC   [9] sum alpha*T*dL/dD
 // ---------------------------------------------------------------------------------------------------------
 // DA = the caller supplied dL/ddepth and/or dL/dalpha.  Topo4D discards depth and alpha (train.py:307), so its backward
 // runs the DA = false instantiation, which carries neither the two extra suffix accumulators nor their products.
@@ -935,7 +950,6 @@ template <bool DA>
 __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
 {
     __shared__ float2 s_xy[kBwdBatch + 1];
-    __shared__ float4 s_co[kBwdBatch];   // raw conic + opacity
     __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
     __shared__ float4 s_cd[kBwdBatch];
     __shared__ uint32_t s_pair[kBwdBatch];
@@ -985,10 +999,11 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
         if (DA && kp.dL_dalpha) dalp = kp.dL_dalpha[(size_t)v * HW + pix];
     }
     float T = T_final;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-    float adr = 0.f, ldp = 0.f, aar = 0.f, last_alpha = 0.f;
-    const float bg_dot = vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2;
-    const float ddelx_dx = 0.5f * kp.W, ddely_dy = 0.5f * kp.H;
+    // Suffix state of the replay.  Upstream keeps one running "colour behind me" per channel (+ depth, + alpha) and dots
+    // it with dL/dpixel afterwards; the recursion is linear, so the dot product is taken FIRST and a single scalar is
+    // carried:  q_i = c_i . dL/dC (+ depth_i dL/dD + dL/dAlpha),  acc <- alpha_prev q_prev + (1 - alpha_prev) acc.
+    float acc = 0.f, last_q = 0.f, last_alpha = 0.f;
+    const float tf_bg = T_final * (vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2);
 
     const uint32_t wave_max = wave_max_u32(last_contributor);
     if (lane == 0) s_wmax[wave] = wave_max;
@@ -1014,7 +1029,6 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
             if (live) {
                 const float4 c = co[g];
                 s_xy[tid] = p;
-                s_co[tid] = c;
                 s_q[tid] = scale_conic(c);
                 s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
                                         __uint_as_float((uint32_t)(key >> 32)));
@@ -1043,7 +1057,10 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
                 else if (wave_max - base < 64u) m[c2] &= (1ull << (wave_max - base)) - 1ull;
             }
             unsigned short *list = s_list[wave];
-            const int nvis = build_visit_list<kBwdBatch / 64, true>(m, list, lane, (unsigned short)kNull);   // back to front
+            int nvis = build_visit_list<kBwdBatch / 64, true>(m, list, lane, (unsigned short)kNull);   // back to front
+#if T4D_ABL == 3
+            nvis = 0;
+#endif
             for (int k = 0; k < nvis; k += 4) {
                 const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
                 const int jj[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
@@ -1069,44 +1086,39 @@ __global__ __launch_bounds__(kBlock) void k_render_bwd(const KP kp)
                     float r[10];
 #pragma unroll
                     for (int q = 0; q < 10; q++) r[q] = 0.f;
+#if T4D_ABL == 2
+                    if (contrib) r[0] = alpha + G + dx + dy;
+                    if (false) {
+#else
                     if (contrib) {
-                        const float4 c = s_co[j];
+#endif
+                        // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
+                        // the splat centre, and w * dL/dC.  Everything that is constant per splat (opacity, conic,
+                        // 0.5*W, -0.5 ...) is applied ONCE per Gaussian after all tiles are summed (k_preprocess_bwd).
                         const float4 cd = s_cd[j];
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
                         T = T * inv;
-                        const float dchannel_dcolor = alpha * T;
-                        const float oma = 1.f - last_alpha;
-                        float dL_dalpha;
-                        ar0 = fmaf(last_alpha, lc0, oma * ar0); lc0 = cd.x;
-                        ar1 = fmaf(last_alpha, lc1, oma * ar1); lc1 = cd.y;
-                        ar2 = fmaf(last_alpha, lc2, oma * ar2); lc2 = cd.z;
-                        dL_dalpha = (cd.x - ar0) * dp0 + (cd.y - ar1) * dp1 + (cd.z - ar2) * dp2;
-                        r[6] = dchannel_dcolor * dp0; r[7] = dchannel_dcolor * dp1; r[8] = dchannel_dcolor * dp2;
-                        if (DA) {
-                            adr = fmaf(last_alpha, ldp, oma * adr); ldp = cd.w;
-                            dL_dalpha += (cd.w - adr) * ddep;
-                            r[9] = dchannel_dcolor * ddep;
-                            aar = fmaf(oma, aar, last_alpha);
-                            dL_dalpha += (1.f - aar) * dalp;
-                        }
-                        dL_dalpha *= T;
+                        const float w = alpha * T;
+                        float q = fmaf(cd.x, dp0, fmaf(cd.y, dp1, cd.z * dp2));
+                        if (DA) q = fmaf(cd.w, ddep, q) + dalp;
+                        acc = fmaf(last_alpha, last_q, (1.f - last_alpha) * acc);
+                        last_q = q;
                         last_alpha = alpha;
-                        dL_dalpha -= T_final * inv * bg_dot;
-                        const float dL_dG = c.w * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * c.x - gdy * c.y;
-                        const float dG_ddely = -gdy * c.z - gdx * c.y;
-                        r[0] = dL_dG * dG_ddelx * ddelx_dx;
-                        r[1] = dL_dG * dG_ddely * ddely_dy;
-                        r[2] = -0.5f * gdx * dx * dL_dG;
-                        r[3] = -gdx * dy * dL_dG;
-                        r[4] = -0.5f * gdy * dy * dL_dG;
-                        r[5] = G * dL_dalpha;
+                        const float dL_dalpha = fmaf(q - acc, T, -tf_bg * inv);
+                        const float e = G * dL_dalpha, ex = e * dx, ey = e * dy;
+                        r[0] = e; r[1] = ex; r[2] = ey;
+                        r[3] = ex * dx; r[4] = ex * dy; r[5] = ey * dy;
+                        r[6] = w * dp0; r[7] = w * dp1; r[8] = w * dp2;
+                        if (DA) r[9] = w * ddep;
                     }
+#if T4D_ABL == 1 || T4D_ABL == 2
+                    if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][j][0] = r[0];
+#else
                     const float tot = reduce10(r, lane);
                     if (my_slot >= 0) s_acc[wave][j][my_slot] = tot;
                     if (j < 64) wrote[0] |= 1ull << j;
                     else wrote[kBwdBatch / 64 - 1] |= 1ull << (j - 64);
+#endif
                 }
             }
         }
@@ -1170,15 +1182,21 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
         const uint32_t npairs = (uint32_t)((x1 - x0) * (y1 - y0));
         const uint32_t base = kp.pair_off[vg];
         const float4 *gp = reinterpret_cast<const float4 *>(kp.grad_pair) + (size_t)v * kp.cap * 3;
-        float X = 0.f, Y = 0.f, Z = 0.f, gdep = 0.f;
+        float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, gdep = 0.f;
         for (uint32_t k = 0; k < npairs; k++) {
             const uint32_t pr = base + k;
             if (pr >= kp.cap) break;
             const float4 a0 = gp[(size_t)pr * 3], a1 = gp[(size_t)pr * 3 + 1], a2 = gp[(size_t)pr * 3 + 2];
-            g2x += a0.x; g2y += a0.y; X += a0.z; Y += a0.w;
-            Z += a1.x; gop += a1.y; grgb[0] += a1.z; grgb[1] += a1.w;
+            S0 += a0.x; S1 += a0.y; S2 += a0.z; S3 += a0.w;
+            S4 += a1.x; S5 += a1.y; grgb[0] += a1.z; grgb[1] += a1.w;
             grgb[2] += a2.x; gdep += a2.y;
         }
+        // per-splat constants applied once (see k_render_bwd): dL/dG = opacity * dL/dalpha, dG/dd = -G * conic * d
+        const float4 cq = kp.conic_opacity[vg];
+        gop = S0;
+        g2x = -cq.w * (cq.x * S1 + cq.y * S2) * (0.5f * kp.W);
+        g2y = -cq.w * (cq.z * S2 + cq.y * S1) * (0.5f * kp.H);
+        const float X = -0.5f * cq.w * S3, Y = -cq.w * S4, Z = -0.5f * cq.w * S5;      // true d/d(conic A, B, C)
 
         const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
         float cov3[6];
