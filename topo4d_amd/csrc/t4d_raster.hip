@@ -631,9 +631,24 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
         const uint32_t off = it.y, n = it.z;
         if (n < 2) break;                                          // items are ordered by length: nothing left
         unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-        if (n <= (uint32_t)kRankSortMax) {
-            // counting sort by rank: keys are unique (index in the low word), so rank = #keys smaller than mine.
-            // One barrier, every LDS read is a wave-wide broadcast.
+        if (n <= (uint32_t)kBlock) {
+            // counting sort by rank, one key per thread: keys are unique (index in the low word), so
+            // rank = #keys smaller than mine.  One barrier, every LDS read is a wave-wide broadcast.
+            const unsigned long long mine = tid < (int)n ? keys[tid] : ~0ull;
+            s_keys[tid] = mine;                                    // padded with +inf up to kBlock
+            __syncthreads();
+            uint32_t rank = 0;
+            if (tid < (int)((n + 63u) & ~63u)) {                   // waves without keys skip the loop
+                const uint32_t n4 = (n + 3u) & ~3u;
+                for (uint32_t i = 0; i < n4; i += 4) {
+                    const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&s_keys[i]);
+                    const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&s_keys[i + 2]);
+                    rank += (ka.x < mine ? 1u : 0u) + (ka.y < mine ? 1u : 0u) + (kb.x < mine ? 1u : 0u) + (kb.y < mine ? 1u : 0u);
+                }
+            }
+            if (tid < (int)n) keys[rank] = mine;
+        } else if (n <= (uint32_t)kRankSortMax) {
+            // same with two keys per thread
             unsigned long long mine[kRankSortMax / kBlock];
 #pragma unroll
             for (int e = 0; e < kRankSortMax / kBlock; e++) {
@@ -1440,18 +1455,23 @@ int device_cus()
     return cus;
 }
 
-// Grid of the per-tile kernels.  They are written as grid-stride loops over the length-ordered tile list, but on
-// MI355X one workgroup per tile (the hardware dispatcher balancing the load dynamically) measured 1.4x faster
-// than a resident grid with static striding, so the default is the full grid.  T4D_PERSISTENT=1 selects the
-// resident grid (CUs x per_cu workgroups) for experiments.
-int tile_grid(int n_tiles, int per_cu)
+// Grid of the per-tile kernels.  They are grid-stride loops over the length-ordered work items, so the grid size is a
+// free choice.  Measured on MI355X (config 2): a RESIDENT grid (CUs x 4-6 workgroups, T4D_PERSISTENT=1) loses 1.3x to
+// the hardware dispatcher's dynamic balancing; one workgroup per tile pays ~25k workgroup launches of which two
+// thirds only find an empty tile; V*T / div workgroups, each taking items b, b+G, b+2G, ... (one from every length
+// class, heavy first), keeps the dynamic balancing and divides the launch overhead.  T4D_TILE_DIV overrides div.
+int tile_grid(int n_tiles, int per_cu, int div)
 {
-    static int persistent = -1;
+    static int persistent = -1, env_div = -1;
     if (persistent < 0) {
         const char *e = getenv("T4D_PERSISTENT");
         persistent = (e && e[0] == '1') ? 1 : 0;
+        const char *d = getenv("T4D_TILE_DIV");
+        env_div = d ? atoi(d) : 0;
     }
-    return persistent ? min(n_tiles, device_cus() * per_cu) : n_tiles;
+    if (persistent) return min(n_tiles, device_cus() * per_cu);
+    if (env_div > 0) div = env_div;
+    return max(min(n_tiles, device_cus() * per_cu), (n_tiles + div - 1) / div);
 }
 
 int check_problem(const T4DProblem *p)
@@ -1589,11 +1609,11 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     }
     T4D_LAUNCH_CHECK("k_scatter");
     { ProfScope ps_(stream, K_SORT_TILES);
-    hipLaunchKernelGGL(k_sort_tiles, dim3(tile_grid(kp.T * p.n_views, 5)), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
-    hipLaunchKernelGGL(k_render_fwd, dim3(tile_grid(kp.T * p.n_views, 6)), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_render_fwd, dim3(tile_grid(kp.T * p.n_views, 6, 2)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
     return T4D_OK;
@@ -1638,9 +1658,9 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
 
     { ProfScope ps_(stream, K_RENDER_BWD);
     if (kp.dL_ddepth || kp.dL_dalpha)
-        hipLaunchKernelGGL(k_render_bwd<true>, dim3(tile_grid(kp.T * p.n_views, 4)), dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL(k_render_bwd<true>, dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
     else
-        hipLaunchKernelGGL(k_render_bwd<false>, dim3(tile_grid(kp.T * p.n_views, 4)), dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL(k_render_bwd<false>, dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
