@@ -21,6 +21,7 @@ The JSON line carries `roofline` (dominant kernel, HIP-event duration, algorithm
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -88,6 +89,8 @@ def main():
     ap.add_argument("--opacity", default="A", choices=["A", "B"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-views", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("T4D_BENCH_STREAMS", "1")),
+                    help="split the views of a step over this many HIP streams (independent views overlap their kernel tails)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,15 +137,31 @@ def main():
             rv.pop("colors_precomp")
         rv_frames.append(rv)
 
-    batch = ViewBatch(views, H, W, 1.0, cfg["sh_degree"] or 0)
+    S = max(1, min(args.streams, V))
+    bounds = [(V * k) // S for k in range(S + 1)]
+    batches = [ViewBatch(views[bounds[k]:bounds[k + 1]].contiguous(), H, W, 1.0, cfg["sh_degree"] or 0) for k in range(S)]
+    dcs = [dc[bounds[k]:bounds[k + 1]].contiguous() for k in range(S)]
+    batch = batches[0]
     losses = torch.zeros(V, device=dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
 
     def step(i):
         rv = rv_frames[i % len(rv_frames)]
-        color, radii, depth, alpha = batch.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
-                                                   rv.get("colors_precomp"), rv.get("shs"))
-        g = batch.backward(dc)
-        view_dot(color, dc, out=losses)     # per-view scalar loss term <colour, dL/dcolour>, one fused pass
+        g = []
+        if S > 1:
+            main = torch.cuda.current_stream(dev)
+            for st in streams:
+                st.wait_stream(main)
+        for k in range(S):
+            with torch.cuda.stream(streams[k]) if S > 1 else contextlib.nullcontext():
+                color, radii, depth, alpha = batches[k].forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                                                                rv.get("colors_precomp"), rv.get("shs"))
+                g.append(batches[k].backward(dcs[k]))
+                # per-view scalar loss term <colour, dL/dcolour>, one fused pass
+                view_dot(color, dcs[k], out=losses[bounds[k]:bounds[k + 1]])
+        if S > 1:
+            for st in streams:
+                main.wait_stream(st)
         if world > 1:
             return t4d_dist.gather_losses(losses), g
         return losses, g
@@ -170,9 +189,11 @@ def main():
     t_enqueue = time.perf_counter() - t0       # host time to enqueue K steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
-    st = batch.fetch_status()
-    if st.overflow:
+    sts = [b.fetch_status() for b in batches]
+    if any(x.overflow for x in sts):
         raise SystemExit("pair arena overflowed during the timed region: result invalid")
+    st = sts[0]
+    total_pairs_all = sum(x.total_pairs for x in sts)
 
     t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -192,7 +213,7 @@ def main():
         torch.cuda.synchronize(dev)
         tp = time.perf_counter() - tp0
         prof = _lib.profile_end()
-        R_view = st.total_pairs / V
+        R_view = total_pairs_all / V
         S = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
         per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, S)
         for name, (ms, n) in prof.items():
@@ -221,7 +242,7 @@ def main():
     if rank == 0:
         views_total = V * args.steps * world
         value = views_total / dt
-        _, total_bytes = algorithmic_bytes(P, st.total_pairs / V, H * W,
+        _, total_bytes = algorithmic_bytes(P, total_pairs_all / V, H * W,
                                            0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4)
         if roofline is not None:
             roofline["pipeline_frac_of_peak"] = round(value / world * total_bytes / 1e9 / PEAK_HBM_GBS, 4)
@@ -243,7 +264,7 @@ def main():
                                    f"opacity scenario {args.opacity}, forward+backward, per-view gradients",
                        "views_per_step_per_gpu": V, "frames": n_frames, "parallelism": f"frame-sharded x{world}",
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
-                       "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4)},
+                       "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4), "hip_streams": S},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -373,11 +373,30 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                         sh_basis(kp.deg, d, bas);
                         const int K = (kp.deg + 1) * (kp.deg + 1);
                         const float *sh = kp.shs + (size_t)g * kp.M * 3;
+                        // a Gaussian's coefficients are 12*M contiguous bytes: fetch them as 16-byte loads when the row
+                        // is 16-byte aligned (M % 4 == 0, e.g. the 16 coefficients of degree 3) instead of 3*K scalar
+                        // loads at a 12*M-byte lane stride
+                        float shl[48];
+                        if ((kp.M & 3) == 0 && kp.M <= 16) {
+                            const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
+#pragma unroll
+                            for (int i = 0; i < 12; i++)
+                                if (i * 4 < K * 3) {
+                                    const float4 t4 = sh4[i];
+                                    shl[4 * i] = t4.x; shl[4 * i + 1] = t4.y; shl[4 * i + 2] = t4.z; shl[4 * i + 3] = t4.w;
+                                }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 48; i++)
+                                if (i < K * 3) shl[i] = sh[i];
+                        }
                         uint32_t cl = 0;
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) {
                             float r = 0.f;
-                            for (int k = 0; k < K; k++) r += bas[k] * sh[k * 3 + ch];
+#pragma unroll
+                            for (int k = 0; k < 16; k++)
+                                if (k < K) r += bas[k] * shl[k * 3 + ch];
                             r += 0.5f;
                             if (r < 0.f) cl |= 1u << ch;
                             kp.rgb[vg * 3 + ch] = fmaxf(r, 0.f);
@@ -1291,16 +1310,44 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
             float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
             float gd[3] = { 0.f, 0.f, 0.f };
             const float gc[3] = { (cl & 1u) ? 0.f : grgb[0], (cl & 2u) ? 0.f : grgb[1], (cl & 4u) ? 0.f : grgb[2] };
-            for (int k = 0; k < kp.M; k++) {
+            if ((kp.M & 3) == 0 && kp.M <= 16) {
+                // 16-byte loads of the coefficients and 16-byte stores of their gradients (rows are 12*M bytes)
+                const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
+                float4 *gsh4 = reinterpret_cast<float4 *>(gsh);
+                float shl[48], o[48];
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    float o = 0.f;
-                    if (k < K) {
-                        const float s = sh[k * 3 + ch];
-                        o = bas[k] * gc[ch];
-                        gd[0] += bx[k] * s * gc[ch]; gd[1] += by[k] * s * gc[ch]; gd[2] += bz[k] * s * gc[ch];
+                for (int i = 0; i < 12; i++)
+                    if (i * 4 < K * 3) {
+                        const float4 t4 = sh4[i];
+                        shl[4 * i] = t4.x; shl[4 * i + 1] = t4.y; shl[4 * i + 2] = t4.z; shl[4 * i + 3] = t4.w;
                     }
-                    gsh[k * 3 + ch] = o;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        float ov = 0.f;
+                        if (k < K) {
+                            const float sv = shl[k * 3 + ch];
+                            ov = bas[k] * gc[ch];
+                            gd[0] += bx[k] * sv * gc[ch]; gd[1] += by[k] * sv * gc[ch]; gd[2] += bz[k] * sv * gc[ch];
+                        }
+                        o[k * 3 + ch] = ov;
+                    }
+#pragma unroll
+                for (int i = 0; i < 12; i++)
+                    if (i * 4 < kp.M * 3) gsh4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+            } else {
+                for (int k = 0; k < kp.M; k++) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        float o = 0.f;
+                        if (k < K) {
+                            const float sv = sh[k * 3 + ch];
+                            o = bas[k] * gc[ch];
+                            gd[0] += bx[k] * sv * gc[ch]; gd[1] += by[k] * sv * gc[ch]; gd[2] += bz[k] * sv * gc[ch];
+                        }
+                        gsh[k * 3 + ch] = o;
+                    }
                 }
             }
             const float dot = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];
@@ -1338,7 +1385,12 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
         }
     } else if (kp.shs) {
         float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
-        for (int k = 0; k < kp.M * 3; k++) gsh[k] = 0.f;
+        if ((kp.M & 3) == 0) {
+            float4 *gsh4 = reinterpret_cast<float4 *>(gsh);
+            for (int i = 0; i < kp.M * 3 / 4; i++) gsh4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int k = 0; k < kp.M * 3; k++) gsh[k] = 0.f;
+        }
     }
 
     kp.dL_dmeans3D[vg * 3] = gm[0]; kp.dL_dmeans3D[vg * 3 + 1] = gm[1]; kp.dL_dmeans3D[vg * 3 + 2] = gm[2];
