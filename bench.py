@@ -202,20 +202,23 @@ def main():
     dt = float(t_max.item())
 
     # ---- per-kernel durations with HIP events (same steps again; keeps `value` free of event overhead) ----
+    # Every rank replays the steps (a step contains the loss all_gather when N > 1, so all ranks must take part);
+    # only rank 0 records events.
     roofline = None
     kernels = {}
+    torch.cuda.synchronize(dev)
     if rank == 0:
-        torch.cuda.synchronize(dev)
         _lib.profile_begin()
-        tp0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize(dev)
-        tp = time.perf_counter() - tp0
+    tp0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    tp = time.perf_counter() - tp0
+    if rank == 0:
         prof = _lib.profile_end()
         R_view = total_pairs_all / V
-        S = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
-        per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, S)
+        sh_bytes = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
+        per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, sh_bytes)
         for name, (ms, n) in prof.items():
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": n,
