@@ -236,3 +236,29 @@ def test_views_batched_equals_views_one_by_one():
         for k in ga:
             if ga[k] is not None:
                 np.testing.assert_array_equal(ga[k][v], gb[k][0])
+
+
+def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
+    """Mesh order is what makes the LDS tile histogram of k_preprocess effective; a random permutation at 1024^2 makes
+    every workgroup's tile bounding box larger than the histogram, so the per-pair global-atomic fallback runs."""
+    H = W = 1024
+    V = 2
+    rv, cams = util.make_scene(60, 80, H, W, V, opacity="B", seed=51)
+    perm = torch.randperm(rv["means3D"].shape[0], generator=torch.Generator().manual_seed(1))
+    rv = {k: v[perm].contiguous() for k, v in rv.items()}
+    from topo4d_amd import scene
+    dc, _, _ = scene.output_cotangents(V, H, W, seed=52)
+    hip, hg, batch = util.hip_render(cams, rv, dc)
+    st = util.decode_state(batch)
+    for v in range(V):
+        r, g = util.c_oracle_render(cams[v], rv, dc[v])
+        np.testing.assert_array_equal(hip["radii"][v], r.radii)
+        os_ = r.state()
+        counts = os_["ranges"][:, 1] - os_["ranges"][:, 0]
+        np.testing.assert_array_equal(st["tile_count"][v], counts)
+        for t in np.nonzero(counts)[0][::7]:
+            off = int(st["tile_off"][v, t])
+            mine = (st["keys"][v, off: off + counts[t]] & np.uint64(0xffffffff)).astype(np.uint32)
+            np.testing.assert_array_equal(mine, os_["point_list"][os_["ranges"][t, 0]: os_["ranges"][t, 1]])
+        check_outputs(hip, r.color, r.depth, r.alpha, v)
+        check_grads(hg, g, v)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""The reference's own call shape: one camera per call through the drop-in module (train.py:303-315,667): P = 8,280 Gaussians
+(Topo4D's mesh), 512x375 image, params2rendervar -> Renderer(cam)(**rv) -> photometric loss -> backward.  Reports
+iterations/s (= views/s at one view per iteration, the reference's schedule) for: the rasterizer alone with a supplied
+dL/dcolor, and the full iteration with the torch loss and with the fused HIP loss.  One JSON line."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import topo4d_amd
+from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+from topo4d_amd import boundary, loss, scene
+
+dev = torch.device("cuda")
+H, W = 512, 375
+p = scene.make_gaussians(69, 120, opacity="A", seed=0)            # 8,280 vertex-bound Gaussians
+params = {k: torch.nn.Parameter(v.to(dev)) for k, v in p.items()}
+cams = scene.camera_rig(H, W, n_views=24, device=dev)
+g = torch.Generator().manual_seed(0)
+gts = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(24)]
+dcs = [(torch.randn(3, H, W, generator=g) / (3 * H * W)).to(dev) for _ in range(24)]
+opt = torch.optim.Adam([{"params": [v], "lr": 1e-4} for v in params.values()], eps=1e-15)
+
+def it_raster(i):
+    rv = boundary.params2rendervar(params)
+    im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+    im.backward(dcs[i % 24])
+def it_torch_loss(i):
+    rv = boundary.params2rendervar(params)
+    im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+    l = loss.photometric_loss_torch(im, gts[i % 24]); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+def it_fused_loss(i):
+    rv = boundary.params2rendervar(params)
+    im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+    l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+
+out = {"workload": "1 view per call, P=8280, 512x375, opacity 1.0 (Topo4D geometry pass shape)"}
+for mode in ("checked", "lazy"):
+    topo4d_amd.set_sync_mode("checked")
+    for name, fn in (("raster_only", it_raster), ("iter_torch_loss", it_torch_loss), ("iter_fused_loss", it_fused_loss)):
+        for i in range(30): fn(i)
+        topo4d_amd.set_sync_mode(mode)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 300
+        for i in range(n): fn(i)
+        torch.cuda.synchronize()
+        out[f"{name}_{mode}_it_per_s"] = round(n / (time.perf_counter() - t0), 1)
+        topo4d_amd.set_sync_mode("checked")
+print(json.dumps(out))
