@@ -1544,6 +1544,8 @@ int check_problem(const T4DProblem *p)
     if (p->n_views > 4095) return fail(T4D_ERR_ARG, "n_views must be <= 4095");
     if ((int64_t)((p->W + T4D_TILE_X - 1) / T4D_TILE_X) * ((p->H + T4D_TILE_Y - 1) / T4D_TILE_Y) > 0xfffff)
         return fail(T4D_ERR_ARG, "image too large: more than 2^20 tiles");
+    if ((int64_t)p->n_views * ((p->W + T4D_TILE_X - 1) / T4D_TILE_X) * ((p->H + T4D_TILE_Y - 1) / T4D_TILE_Y) > (1LL << 30))
+        return fail(T4D_ERR_ARG, "n_views * tiles exceeds 2^30 work items: split the batch");
     if (p->pair_capacity < 1 || p->pair_capacity > 0x7fffffffLL) return fail(T4D_ERR_ARG, "pair_capacity out of range");
     if (p->sh_coeffs < 0 || p->sh_degree < 0 || p->sh_degree > 3) return fail(T4D_ERR_ARG, "sh_degree must be 0..3");
     if (p->sh_coeffs > 0 && p->sh_coeffs < (p->sh_degree + 1) * (p->sh_degree + 1))
