@@ -153,6 +153,27 @@ int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im,
                          const float *cam_c, const float *view_weight, float *loss, float *dL_dim, float *dL_dcam_m,
                          float *dL_dcam_c, void *scratch, size_t scratch_bytes, void *hip_stream);
 
+/* Fused optimiser step of Topo4D's loop: torch.optim.Adam (one group per tensor, train.py:272-297) for up to
+ * T4D_ADAM_MAX_TENSORS tensors in ONE launch, followed by the per-iteration region freezes of train.py:676-700
+ * (`params[name][mask] = values`) expressed as a per-row pin mask + pinned values.  grad == NULL: the tensor only gets its
+ * pins (torch skips parameters without a gradient). */
+#define T4D_ADAM_MAX_TENSORS 12
+typedef struct T4DAdamTensor {
+    float *param;               /* [rows, width] updated in place */
+    const float *grad;          /* same shape or NULL */
+    float *exp_avg, *exp_avg_sq;/* Adam state, same shape (required when grad != NULL) */
+    const uint8_t *pin_mask;    /* [rows] or NULL */
+    const float *pin_values;    /* [rows, width] (read where pin_mask != 0) or NULL */
+    int64_t rows;
+    int32_t width;
+    float lr;
+    int32_t step;               /* 1-based count of the gradient steps THIS tensor has taken, this one included (torch keeps
+                                   the step per parameter; a tensor skipped for lack of a gradient does not advance) */
+    int32_t reserved;
+} T4DAdamTensor;
+int t4d_adam_pin_step(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
+                      void *hip_stream);
+
 /* UV-space texture bake (BASELINE config 5): drop-in for the reference's CPU rasterizer
  *     void _render_colors_core(float* image, float* vertices, int* triangles, float* colors, float* depth_buffer,
  *                              int nver, int ntri, int h, int w, int c)        face3d/mesh/cython/mesh_core.h:63-69

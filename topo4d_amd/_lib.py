@@ -26,6 +26,7 @@ EXPORTS = (
     "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
     "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end", "t4d_view_dot", "t4d_view_dot_scratch_bytes",
     "t4d_texture_bake", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
+    "t4d_adam_pin_step",
 )
 
 
@@ -58,6 +59,15 @@ class T4DBackwardIO(C.Structure):
 
 class T4DKernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_int64)]
+
+
+T4D_ADAM_MAX_TENSORS = 12
+
+
+class T4DAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("pin_mask", C.c_void_p), ("pin_values", C.c_void_p), ("rows", C.c_int64), ("width", C.c_int32),
+                ("lr", C.c_float), ("step", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ExtensionMissing(RuntimeError):
@@ -111,6 +121,8 @@ def load():
     lib.t4d_photometric_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.t4d_photometric_loss.restype = C.c_int
     lib.t4d_photometric_loss.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p]
+    lib.t4d_adam_pin_step.restype = C.c_int
+    lib.t4d_adam_pin_step.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.t4d_profile_begin.restype = C.c_int
     lib.t4d_profile_end.restype = C.c_int
     lib.t4d_profile_end.argtypes = [C.POINTER(T4DKernelTime), C.c_int, C.POINTER(C.c_int)]

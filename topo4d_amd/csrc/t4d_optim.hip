@@ -1,0 +1,89 @@
+// t4d_optim.hip — fused multi-tensor Adam step + region pins for Topo4D's per-view optimisation loop
+// (SURVEY.md §8f rank 3).
+//
+// One launch replaces `optimizer.step()` (torch.optim.Adam with one parameter group per tensor, eps = 1e-15,
+// reference train.py:272-297, :672) AND the ~16 masked assignments that follow it in every iteration
+// (`params[name][region_mask] = frozen_values`, train.py:676-700): each tensor may carry a per-row pin mask and the
+// values its pinned rows must hold after the step.  Arithmetic follows torch.optim.Adam (no weight decay, no amsgrad):
+//     m <- m + (1-b1)(g - m);  v <- b2 v + (1-b2) g^2;  p <- p - (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// with the bias corrections evaluated on the host in double precision, as torch does.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/topo4d_raster.h"
+
+#define T4D_EXPORT extern "C" __attribute__((visibility("default")))
+int t4d_internal_fail(int code, const char *fmt, const char *a);
+
+namespace {
+
+constexpr int kMaxTensors = T4D_ADAM_MAX_TENSORS;
+constexpr int kBlock = 256;
+
+struct AdamArgs {
+    T4DAdamTensor t[kMaxTensors];
+    long long first_block[kMaxTensors + 1];    // exclusive prefix of the per-tensor block counts
+    float step_size[kMaxTensors];              // lr / (1 - beta1^t)
+    float inv_bc2_sqrt[kMaxTensors];           // 1 / sqrt(1 - beta2^t)
+    int n;
+    float beta1, beta2, eps;
+};
+
+__global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxTensors; i++) k += (i < A.n && (long long)blockIdx.x >= A.first_block[i]) ? 1 : 0;
+    const T4DAdamTensor &T = A.t[k];
+    const long long i = ((long long)blockIdx.x - A.first_block[k]) * kBlock + threadIdx.x;
+    const long long numel = T.rows * T.width;
+    if (i >= numel) return;
+    float p = T.param[i];
+    if (T.grad) {
+        const float g = T.grad[i];
+        float m = T.exp_avg[i], v = T.exp_avg_sq[i];
+        m = fmaf(1.f - A.beta1, g - m, m);
+        v = fmaf(1.f - A.beta2, g * g, A.beta2 * v);
+        T.exp_avg[i] = m;
+        T.exp_avg_sq[i] = v;
+        const float denom = sqrtf(v) * A.inv_bc2_sqrt[k] + A.eps;
+        p = p - A.step_size[k] * (m / denom);
+    }
+    if (T.pin_mask && T.pin_mask[i / T.width]) p = T.pin_values[i];
+    T.param[i] = p;
+}
+
+}  // namespace
+
+T4D_EXPORT int t4d_adam_pin_step(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps,
+                                 void *hip_stream)
+{
+    if (!tensors || n_tensors < 1 || n_tensors > kMaxTensors)
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: 1..T4D_ADAM_MAX_TENSORS tensors%s", "");
+    AdamArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n_tensors; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
+    long long blocks = 0;
+    for (int k = 0; k < n_tensors; k++) {
+        const T4DAdamTensor &t = tensors[k];
+        if (!t.param || t.rows < 0 || t.width < 1 || (t.grad && (!t.exp_avg || !t.exp_avg_sq)) || ((t.pin_mask == nullptr) != (t.pin_values == nullptr)))
+            return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: inconsistent tensor descriptor%s", "");
+        if (t.grad && t.step < 1) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: step must be >= 1%s", "");
+        A.t[k] = t;
+        const double st = t.grad ? (double)t.step : 1.0;
+        const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
+        A.step_size[k] = (float)((double)t.lr / bc1);
+        A.inv_bc2_sqrt[k] = (float)(1.0 / sqrt(bc2));
+        A.first_block[k] = blocks;
+        blocks += (t.rows * t.width + kBlock - 1) / kBlock;
+    }
+    A.first_block[n_tensors] = blocks;
+    if (blocks == 0) return T4D_OK;
+    if (blocks > 0x7fffffffLL) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: too many elements%s", "");
+    hipLaunchKernelGGL(k_adam_pin, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_adam_pin_step launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}

@@ -1,0 +1,124 @@
+"""
+Fused Adam + region pins — host mirror of the optimiser plumbing Topo4D runs after every rendered view
+(reference train.py:272-297 `initialize_optimizer`, helpers.py:801-804 `update_optimizer`, train.py:672-700
+`optimizer.step()` followed by the masked "freeze" assignments).
+
+`FusedAdamPins` keeps torch.optim.Adam's surface for what the loop touches (`param_groups` with 'name'/'lr'/'params',
+`step()`, `zero_grad(set_to_none)`, `state`) and adds `set_pin(name, index, values)`: rows that must hold fixed values
+after every step.  step() is ONE kernel launch (`t4d_adam_pin_step`) for all tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+
+class FusedAdamPins:
+    def __init__(self, param_groups: List[dict], lr: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-15):
+        if len(param_groups) > _lib.T4D_ADAM_MAX_TENSORS:
+            raise ValueError(f"at most {_lib.T4D_ADAM_MAX_TENSORS} tensors per fused step")
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            if len(g["params"]) != 1:
+                raise ValueError("one tensor per group (as initialize_optimizer builds them, train.py:292-295)")
+            g.setdefault("lr", lr)
+            g.setdefault("name", f"param{len(self.param_groups)}")
+            self.param_groups.append(g)
+        self.betas, self.eps = betas, eps
+        self.state: Dict[torch.Tensor, dict] = {}
+        self._pins: Dict[str, tuple] = {}
+
+    # -- pins ------------------------------------------------------------------------------------------------
+    def set_pin(self, name: str, index, values) -> None:
+        """After every step, rows `index` (bool mask or integer indices) of parameter `name` hold `values`
+        (broadcastable to [n_selected, width]).  Later calls for the same name override earlier ones on the rows they
+        share — the order of the assignments in train.py:676-700."""
+        p = self._param(name)
+        rows, width = p.shape[0], p[0].numel() if p.dim() > 1 else 1
+        mask, vals = self._pins.get(name, (None, None))
+        if mask is None:
+            mask = torch.zeros(rows, dtype=torch.uint8, device=p.device)
+            vals = torch.zeros(rows, width, dtype=torch.float32, device=p.device)
+        idx = torch.as_tensor(index, device=p.device)
+        if idx.dtype == torch.bool:
+            sel = idx
+        else:
+            sel = torch.zeros(rows, dtype=torch.bool, device=p.device)
+            sel[idx.long()] = True
+        n_sel = int(sel.sum())
+        vt = torch.as_tensor(values, dtype=torch.float32, device=p.device)
+        if vt.numel() == n_sel * width:
+            vt = vt.reshape(n_sel, width)                       # one row of values per selected row, in index order
+            if idx.dtype != torch.bool:                         # integer indices may be unsorted: place by index
+                full = torch.zeros(rows, width, dtype=torch.float32, device=p.device)
+                full[idx.long()] = vt
+                vt = full[sel]
+        else:
+            vt = torch.broadcast_to(vt.reshape(-1, width) if vt.numel() >= width else vt.reshape(-1, 1), (n_sel, width))
+        mask = mask.clone()
+        vals = vals.clone()
+        mask[sel] = 1
+        vals[sel] = vt
+        self._pins[name] = (mask, vals)
+
+    def clear_pin(self, name: Optional[str] = None) -> None:
+        if name is None:
+            self._pins.clear()
+        else:
+            self._pins.pop(name, None)
+
+    def _param(self, name: str) -> torch.Tensor:
+        for g in self.param_groups:
+            if g["name"] == name:
+                return g["params"][0]
+        raise KeyError(name)
+
+    # -- torch.optim surface ------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for g in self.param_groups:
+            p = g["params"][0]
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self) -> None:
+        lib = _lib.load()
+        arr = (_lib.T4DAdamTensor * len(self.param_groups))()
+        keep = []
+        dev = None
+        for k, g in enumerate(self.param_groups):
+            p = g["params"][0]
+            if not p.is_cuda:
+                raise RuntimeError("topo4d_amd has no CPU path: parameters must live on a HIP device")
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise ValueError("parameters must be contiguous float32")
+            dev = p.device
+            rows = p.shape[0] if p.dim() > 0 else 1
+            width = p.numel() // max(rows, 1)
+            grad = None
+            if p.grad is not None:
+                grad = p.grad.contiguous()
+                st = self.state.setdefault(p, {})
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] = st.get("step", 0) + 1           # per parameter, as torch.optim.Adam counts it
+                keep.append(grad)
+            st = self.state.get(p, {})
+            mask, vals = self._pins.get(g["name"], (None, None))
+            ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            arr[k] = _lib.T4DAdamTensor(ptr(p), ptr(grad), ptr(st.get("exp_avg")) if grad is not None else None,
+                                        ptr(st.get("exp_avg_sq")) if grad is not None else None, ptr(mask), ptr(vals), rows,
+                                        width, float(g["lr"]), int(st.get("step", 0)) if grad is not None else 0, 0)
+        rc = lib.t4d_adam_pin_step(arr, len(self.param_groups), float(self.betas[0]), float(self.betas[1]),
+                                   float(self.eps), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"t4d_adam_pin_step failed (code {rc}): {_lib.last_error()}")
