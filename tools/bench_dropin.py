@@ -18,7 +18,12 @@ cams = scene.camera_rig(H, W, n_views=24, device=dev)
 g = torch.Generator().manual_seed(0)
 gts = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(24)]
 dcs = [(torch.randn(3, H, W, generator=g) / (3 * H * W)).to(dev) for _ in range(24)]
-opt = torch.optim.Adam([{"params": [v], "lr": 1e-4} for v in params.values()], eps=1e-15)
+from topo4d_amd.optim import FusedAdamPins
+groups = [{"params": [v], "name": k, "lr": 1e-4} for k, v in params.items()]
+opt = torch.optim.Adam(groups, eps=1e-15)
+fopt = FusedAdamPins(groups, eps=1e-15)
+fopt.set_pin("means3D", torch.arange(0, 8280, 5), params["means3D"][::5].detach().clone())      # a "static region"
+static_idx = torch.arange(0, 8280, 5, device=dev); static_vals = params["means3D"][::5].detach().clone()
 
 def it_raster(i):
     rv = boundary.params2rendervar(params)
@@ -33,10 +38,23 @@ def it_fused_loss(i):
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
     l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
 
+def it_fused_all(i):
+    rv = boundary.params2rendervar(params)
+    im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+    l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); fopt.step(); fopt.zero_grad(set_to_none=True)
+def it_torch_all(i):
+    rv = boundary.params2rendervar(params)
+    im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+    l = loss.photometric_loss_torch(im, gts[i % 24]); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        for _ in range(8):                                   # train.py:676-700: ~8-16 masked assignments per iteration
+            params["means3D"][static_idx] = static_vals
+
 out = {"workload": "1 view per call, P=8280, 512x375, opacity 1.0 (Topo4D geometry pass shape)"}
 for mode in ("checked", "lazy"):
     topo4d_amd.set_sync_mode("checked")
-    for name, fn in (("raster_only", it_raster), ("iter_torch_loss", it_torch_loss), ("iter_fused_loss", it_fused_loss)):
+    for name, fn in (("raster_only", it_raster), ("iter_torch_loss", it_torch_loss), ("iter_fused_loss", it_fused_loss),
+                     ("iter_torch_loss_adam_freezes", it_torch_all), ("iter_fused_loss_adam_pins", it_fused_all)):
         for i in range(30): fn(i)
         topo4d_amd.set_sync_mode(mode)
         torch.cuda.synchronize(); t0 = time.perf_counter()
