@@ -174,6 +174,14 @@ typedef struct T4DAdamTensor {
 int t4d_adam_pin_step(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
                       void *hip_stream);
 
+/* Dense-attribute interpolation: helpers.py:237-253 `compute_vertex_attribute_by_weight_2` on the device (Topo4D runs it in
+ * numpy after a device->host copy every frame, train.py:504-506).  out [n_coarse+n_dense, width]: the first n_coarse rows
+ * copy `attribute` [n_coarse, width]; dense row d = sum_k attribute[quad_faces[vertex_father[d]][k]] * weight[d][k], k < 4,
+ * accumulated in float64 like numpy and rounded to float32 once (bit-identical to the reference followed by `.float()`). */
+int t4d_dense_interpolate(const float *attribute, const int32_t *quad_faces /* [n_quads,4] */,
+                          const int32_t *vertex_father /* [n_dense] */, const double *weight /* [n_dense,4] */,
+                          int64_t n_coarse, int64_t n_dense, int32_t width, float *out, void *hip_stream);
+
 /* UV-space texture bake (BASELINE config 5): drop-in for the reference's CPU rasterizer
  *     void _render_colors_core(float* image, float* vertices, int* triangles, float* colors, float* depth_buffer,
  *                              int nver, int ntri, int h, int w, int c)        face3d/mesh/cython/mesh_core.h:63-69

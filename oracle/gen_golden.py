@@ -11,6 +11,7 @@ G2  helpers.params2rendervar      (helpers.py:91-100)  seeded P=64 parameter dic
 G3  helpers.l1_loss_v1 + external.calc_ssim (helpers.py:115-116, external.py:73-116) on seeded 3x64x64 pairs,
     with the gradient of 0.8*L1 + 0.2*(1-SSIM) w.r.t. the rendered image (train.py:315)
 G4  helpers.eval_sh               (helpers.py:865-922) degrees 0..3 on seeded [P=32,3,16] coefficients
+G7  helpers.compute_vertex_attribute_by_weight_2 (helpers.py:237-253) on a seeded quad mesh
 G6  SELF-GENERATED (not reference-derived): forward outputs + all gradients of oracle/torch_oracle.py (float64)
     on a 64x64 / P=200 scene; pins the oracle against accidental edits.
 The rasterizer itself has no reference-derived golden vectors: its source is absent from /root/reference
@@ -146,6 +147,18 @@ def main():
     g4["C3"] = np.array(helpers.C3)
     g4["RGB2SH_half"] = helpers.RGB2SH(torch.tensor([0.0, 0.5, 1.0])).numpy()
     np.savez(os.path.join(OUT, "g4_eval_sh.npz"), **g4)
+
+    # ---- G7: helpers.compute_vertex_attribute_by_weight_2 (helpers.py:237-253) ---------------------------------
+    n_c, n_q, n_d = 50, 30, 400
+    quads = rng.integers(0, n_c, size=(n_q, 4)).astype(np.int64)
+    father = rng.integers(0, n_q, size=(n_d, 1)).astype(np.int64)
+    wgt = rng.uniform(size=(n_d, 4)); wgt /= wgt.sum(1, keepdims=True)
+    attr = rng.normal(size=(n_c, 3)).astype(np.float32)
+    variables = {"dense_vertex_father": father, "dense_vertex_weight": wgt, "dense_quad_faces": quads,
+                 "dense_vertex": np.zeros((n_c + n_d, 3))}
+    dense = helpers.compute_vertex_attribute_by_weight_2(variables, attr)
+    np.savez(os.path.join(OUT, "g7_dense_interp.npz"), quads=quads, father=father, weight=wgt, attr=attr, dense=dense,
+             dense_f32=torch.tensor(dense).float().numpy())
 
     # ---- G6 (self-generated) --------------------------------------------------------------------------------
     from oracle import torch_oracle as TO

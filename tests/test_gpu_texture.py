@@ -69,3 +69,24 @@ def test_bake_texture_bytes_match_reference_pipeline():
     ref = TX.render_colors_cpu(uvc, faces, colors, res, res)      # helpers.py:956
     np.testing.assert_array_equal(mine, (ref * 255).astype(np.uint8))
     assert mine.dtype == np.uint8 and mine.shape == (res, res, 3)
+
+
+def test_dense_attribute_interpolation_bit_exact_vs_reference_golden():
+    """G7 = outputs of the real helpers.compute_vertex_attribute_by_weight_2 (float64) and their `.float()` cast."""
+    import os
+    from topo4d_amd import texture
+    g = np.load(os.path.join(os.path.dirname(G), "g7_dense_interp.npz"))
+    variables = {"dense_vertex_father": g["father"], "dense_vertex_weight": g["weight"], "dense_quad_faces": g["quads"],
+                 "dense_vertex": np.zeros((g["dense"].shape[0], 3))}
+    out = texture.compute_vertex_attribute_by_weight(variables, torch.tensor(g["attr"]).cuda())
+    np.testing.assert_array_equal(out.cpu().numpy(), g["dense_f32"])
+    # plain numpy restatement on fresh data, bigger
+    rng = np.random.default_rng(1)
+    n_c, n_q, n_d = 8280, 5000, 200000
+    quads = rng.integers(0, n_c, size=(n_q, 4)); father = rng.integers(0, n_q, size=(n_d, 1))
+    w = rng.uniform(size=(n_d, 4)); attr = rng.normal(size=(n_c, 4)).astype(np.float32)
+    ref = np.zeros((n_c + n_d, 4)); ref[:n_c] = attr
+    ref[n_c:] = np.sum(attr[quads[father].squeeze(1)] * w[..., None], axis=1)
+    v2 = {"dense_vertex_father": father, "dense_vertex_weight": w, "dense_quad_faces": quads, "dense_vertex": ref}
+    out = texture.compute_vertex_attribute_by_weight(v2, torch.tensor(attr).cuda())
+    np.testing.assert_array_equal(out.cpu().numpy(), ref.astype(np.float32))

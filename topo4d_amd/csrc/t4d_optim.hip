@@ -87,3 +87,47 @@ T4D_EXPORT int t4d_adam_pin_step(const T4DAdamTensor *tensors, int32_t n_tensors
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_adam_pin_step launch: %s", hipGetErrorString(e));
     return T4D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Dense-attribute interpolation: restates reference helpers.py:237-253
+// `compute_vertex_attribute_by_weight_2` — every UV-densified vertex is the weighted sum of the four corners of its
+// "father" quad — which Topo4D runs in numpy on the host once per frame after a device->host copy (train.py:504-506).
+// The reference accumulates in float64 (np.zeros / np.sum defaults) and the result is cast to float32 afterwards
+// (train.py:259-261 `.float()`); the kernel does the same, so the float32 output is bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_dense_interp(const float *attr, const int32_t *quad_faces, const int32_t *father,
+                                                      const double *weight, long long n_coarse, long long n_dense, int width,
+                                                      float *out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (n_coarse + n_dense) * width;
+    if (i >= total) return;
+    const long long row = i / width;
+    const int c = (int)(i - row * width);
+    if (row < n_coarse) { out[i] = attr[i]; return; }
+    const long long d = row - n_coarse;
+    const int32_t *q = quad_faces + 4 * (long long)father[d];
+    const double *w = weight + 4 * d;
+    double s = (double)attr[(long long)q[0] * width + c] * w[0];            // np.sum over 4 terms: left to right
+    s += (double)attr[(long long)q[1] * width + c] * w[1];
+    s += (double)attr[(long long)q[2] * width + c] * w[2];
+    s += (double)attr[(long long)q[3] * width + c] * w[3];
+    out[i] = (float)s;
+}
+}  // namespace
+
+T4D_EXPORT int t4d_dense_interpolate(const float *attribute, const int32_t *quad_faces, const int32_t *vertex_father,
+                                     const double *weight, int64_t n_coarse, int64_t n_dense, int32_t width, float *out,
+                                     void *hip_stream)
+{
+    if (!attribute || !out || n_coarse < 0 || n_dense < 0 || width < 1 || (n_dense > 0 && (!quad_faces || !vertex_father || !weight)))
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_dense_interpolate: bad arguments%s", "");
+    const long long total = (n_coarse + n_dense) * width;
+    if (total == 0) return T4D_OK;
+    hipLaunchKernelGGL(k_dense_interp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, attribute,
+                       quad_faces, vertex_father, weight, (long long)n_coarse, (long long)n_dense, (int)width, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_dense_interpolate launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}

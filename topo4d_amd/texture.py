@@ -94,3 +94,33 @@ def write_texture(path, uvs, colors, faces, res: int = 1024, device="cuda") -> N
     """helpers.py:953-960 (`io.imsave` replaced by PIL, which this image has)."""
     from PIL import Image
     Image.fromarray(np.squeeze(bake_texture(uvs, colors, faces, res, device))).save(path)
+
+
+def compute_vertex_attribute_by_weight(variables, attribute: torch.Tensor) -> torch.Tensor:
+    """helpers.py:237-253 `compute_vertex_attribute_by_weight_2` on the device: `attribute` [n_coarse, d] (float32, GPU) ->
+    [n_dense_total, d] float32, without the per-frame device->host->device round trip of train.py:504-506.
+    `variables` holds the same keys the reference uses: 'dense_vertex_father' [n_dense(,1)], 'dense_vertex_weight'
+    [n_dense,4], 'dense_quad_faces' [n_quads,4], 'dense_vertex' (only its length is used).  The index/weight arrays are
+    uploaded once and cached on the dict."""
+    if not attribute.is_cuda:
+        raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+    lib = _lib.load()
+    dev = attribute.device
+    cache = variables.setdefault("_t4d_dense_cache", {})
+    if cache.get("device") != dev:
+        cache["father"] = torch.as_tensor(np.asarray(variables["dense_vertex_father"]).reshape(-1), dtype=torch.int32).to(dev)
+        cache["weight"] = torch.as_tensor(np.asarray(variables["dense_vertex_weight"], dtype=np.float64)).to(dev).contiguous()
+        cache["quads"] = torch.as_tensor(np.asarray(variables["dense_quad_faces"]), dtype=torch.int32).to(dev).contiguous()
+        cache["device"] = dev
+    attr = attribute.detach().float().contiguous()
+    n_coarse, width = int(attr.shape[0]), int(attr.shape[1])
+    n_total = int(np.asarray(variables["dense_vertex"]).shape[0])
+    n_dense = n_total - n_coarse
+    assert n_dense == cache["father"].numel() == cache["weight"].shape[0]
+    out = torch.empty(n_total, width, dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.t4d_dense_interpolate(p(attr), p(cache["quads"]), p(cache["father"]), p(cache["weight"]), n_coarse, n_dense, width,
+                                   p(out), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != T4D_OK:
+        raise RuntimeError(f"t4d_dense_interpolate failed (code {rc}): {_lib.last_error()}")
+    return out
