@@ -44,7 +44,10 @@ namespace {
 #endif
 constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave64)
 constexpr int kFwdBatch = 256;       // splats staged in LDS per round of the forward blend
-constexpr int kBwdBatch = 128;       // splats staged per round of the backward replay
+#ifndef T4D_BWD_BATCH
+#define T4D_BWD_BATCH 128
+#endif
+constexpr int kBwdBatch = T4D_BWD_BATCH;   // splats staged per round of the backward replay (64 or 128)
 constexpr int kSortLdsCap = 4096;    // keys sorted in LDS (32 KiB); longer bins use the global-memory path
 constexpr int kRankSortMax = 512;    // bins up to this length are sorted by counting ranks (no barriers)
 constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     __shared__ uint32_t s_wmax[4];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][kBwdBatch + 4];
     constexpr int kNull = kBwdBatch;
-    static_assert(kBwdBatch == 128, "the slab-written masks below assume two 64-splat chunks per batch");
+    static_assert(kBwdBatch == 64 || kBwdBatch == 128, "the slab-written masks below assume one or two 64-splat chunks per batch");
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -1160,7 +1163,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #else
                     const float tot = reduce10(r, lane);
                     if (my_slot >= 0) s_acc[wave][j][my_slot] = tot;
-                    if (j < 64) wrote[0] |= 1ull << j;
+                    if (kBwdBatch == 64 || j < 64) wrote[0] |= 1ull << (j & 63);
                     else wrote[kBwdBatch / 64 - 1] |= 1ull << (j - 64);
 #endif
                 }
