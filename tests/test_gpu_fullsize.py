@@ -192,3 +192,40 @@ def test_c2_full_size_sampled_views_against_c_oracle(c2):
         assert (c2["st"]["n_contrib"][v] == os_["n_contrib"]).mean() > 1 - 2e-4
         check_outputs(c2["out"], r.color, r.depth, r.alpha, v)
         check_grads(c2["g"], gref, v)
+
+
+def test_module_accepts_what_upstream_accepts():
+    """Non-contiguous / float64 inputs, [P] vs [P,1] opacities, SH and precomputed-covariance paths, no_grad renders
+    (train.py:463,484), all through the drop-in module."""
+    import topo4d_amd
+    from oracle import torch_oracle as TO
+    from topo4d_amd import scene
+    H = W = 64
+    rv, cams = util.make_scene(10, 16, H, W, 2, opacity="B", seed=8)
+    cam = util.to_device(cams, "cuda")[0]
+    R = topo4d_amd.GaussianRasterizer(cam)
+    base = {k: v.cuda() for k, v in rv.items()}
+    ref = [t.clone() for t in R(base["means3D"], None, base["opacities"], colors_precomp=base["colors_precomp"],
+                                scales=base["scales"], rotations=base["rotations"])]
+    # non-contiguous means (every other row of a bigger tensor), float64 scales, flat opacities
+    big = torch.zeros(320, 3, device="cuda"); big[::2] = base["means3D"]
+    out = R(big[::2], torch.zeros(160, 3, device="cuda"), base["opacities"].reshape(-1), colors_precomp=base["colors_precomp"],
+            scales=base["scales"].double(), rotations=base["rotations"])
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    with torch.no_grad():                                    # report_progress-style render
+        out = R(**{**base, "means2D": torch.zeros(160, 3, device="cuda")})
+    assert torch.equal(out[0], ref[0]) and not out[0].requires_grad
+    # SH colours through the module: degree 0 with DC = (rgb - 0.5)/C0 reproduces the precomputed colours
+    sh = ((base["colors_precomp"] - 0.5) / 0.28209479177387814)[:, None, :].contiguous()
+    out = topo4d_amd.GaussianRasterizer(cam._replace(sh_degree=0))(base["means3D"], None, base["opacities"], shs=sh,
+                                                                   scales=base["scales"], rotations=base["rotations"])
+    assert (out[0] - ref[0]).abs().max() < 1e-5
+    # precomputed covariance through the module
+    Rm = TO.quat_to_rot(rv["rotations"].double()); RS = Rm * rv["scales"].double()[:, None, :]; S = RS @ RS.transpose(1, 2)
+    cov = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).float().cuda().requires_grad_(True)
+    out = R(base["means3D"], None, base["opacities"], colors_precomp=base["colors_precomp"], cov3D_precomp=cov)
+    assert (out[0] - ref[0]).abs().max() < 1e-5
+    out[0].sum().backward()
+    assert cov.grad is not None and torch.isfinite(cov.grad).all() and cov.grad.abs().max() > 0
+    assert R.markVisible(base["means3D"]).all()
