@@ -100,12 +100,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists by design)")
+    if os.environ.get("T4D_BENCH_SHARE_GPU") == "1":                   # dry run: several ranks on one GPU (never timed runs)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("T4D_DIST_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm; gloo only for dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import topo4d_amd
     from topo4d_amd import ViewBatch, _lib, boundary, dist as t4d_dist, pack_views, scene
@@ -143,11 +149,21 @@ def main():
     dcs = [dc[bounds[k]:bounds[k + 1]].contiguous() for k in range(S)]
     batch = batches[0]
     losses = torch.zeros(V, device=dev)
+    # multi-GPU: the loss all_gather of step i overlaps with step i+1 (double-buffered, waited on two steps later)
+    loss_bufs = [torch.zeros(V, device=dev), torch.zeros(V, device=dev)]
+    gath_bufs = [torch.zeros(V * world, device=dev), torch.zeros(V * world, device=dev)]
+    pending = [None, None]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
 
     def step(i):
+        nonlocal losses
         rv = rv_frames[i % len(rv_frames)]
         g = []
+        if world > 1:
+            if pending[i % 2] is not None:
+                pending[i % 2].wait()
+                pending[i % 2] = None
+            losses = loss_bufs[i % 2]
         if S > 1:
             main = torch.cuda.current_stream(dev)
             for st in streams:
@@ -163,13 +179,25 @@ def main():
             for st in streams:
                 main.wait_stream(st)
         if world > 1:
-            return t4d_dist.gather_losses(losses), g
+            out, work = t4d_dist.gather_losses_async(losses, gath_bufs[i % 2])
+            pending[i % 2] = work
+            return out, g
         return losses, g
 
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+
     def barrier():
+        drain()
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local_rank])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     # warm-up: first call is "checked" (learns the pair-arena capacity), the rest of the run is lazy (no host sync)
@@ -239,8 +267,7 @@ def main():
                     "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels}
 
     if world > 1:
-        import torch.distributed as dist
-        dist.barrier(device_ids=[local_rank])
+        barrier()
 
     if rank == 0:
         views_total = V * args.steps * world

@@ -58,3 +58,22 @@ def test_gather_losses_world2_gloo(n_units):
 def test_single_process_gather_is_identity():
     x = torch.arange(5.0)
     assert t4d_dist.gather_losses(x) is x
+
+
+def _worker_async(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        local = torch.tensor([rank * 10.0 + k for k in range(3)])
+        out = torch.empty(3 * world)
+        out, work = t4d_dist.gather_losses_async(local, out)
+        if work is not None:
+            work.wait()
+        assert torch.equal(out.view(world, -1), torch.tensor([[r * 10.0 + k for k in range(3)] for r in range(world)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_gather_world2_gloo():
+    mp.spawn(_worker_async, args=(2, _free_port()), nprocs=2, join=True)

@@ -32,6 +32,8 @@ def gather_losses(local: torch.Tensor, n_units: int = None) -> torch.Tensor:
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
+    if local.is_cuda and dist.get_backend() != "nccl":        # gloo dry runs: stage through the host
+        return gather_losses(local.cpu(), n_units).to(local.device)
     if n_units is None:                       # equal shards
         out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
@@ -48,6 +50,24 @@ def gather_losses(local: torch.Tensor, n_units: int = None) -> torch.Tensor:
     for r in range(world):
         res[r::world] = out[r, : sizes[r]]
     return res
+
+
+def gather_losses_async(local: torch.Tensor, out: torch.Tensor):
+    """Equal-shard loss gather that does NOT block the compute stream: returns (out, work).  The collective is ordered
+    after the work already enqueued on the current stream; kernels enqueued afterwards overlap with it.  `out` must hold
+    world*local.numel() elements in rank-major order (out.view(world,-1).t() is unit order) and, like `local`, must not be
+    rewritten before `work.wait()`."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        out[: local.numel()].copy_(local)
+        return out, None
+    if local.is_cuda and dist.get_backend() != "nccl":        # gloo dry runs: synchronous, through the host
+        tmp = torch.empty(out.numel(), dtype=local.dtype)
+        dist.all_gather_into_tensor(tmp, local.cpu().contiguous())
+        out.copy_(tmp)
+        return out, None
+    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=True)
+    return out, work
 
 
 def all_reduce_grads(grads: Sequence[torch.Tensor]) -> None:
