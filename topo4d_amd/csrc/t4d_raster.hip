@@ -4,23 +4,26 @@
 // train.py:307,388,463,484 (boundary: helpers.py:63-112).  Written from the published algorithm (SURVEY.md
 // Appendix A) for wave64 / LDS / 8-XCD hardware; it is not a translation of the CUDA sources (which are not
 // even present under /root/reference).  Differences in STRUCTURE from upstream, all result-preserving:
-//   * V views of the same Gaussians go through one set of launches (blockIdx.z / .y = view);
-//   * binning is count -> per-view tile scan -> scatter into per-tile bins -> per-tile LDS bitonic sort on the
-//     64-bit key (depth bits << 32 | Gaussian index).  That reproduces upstream's order (stable radix sort on
-//     tile|depth of pairs emitted in index order) without a global sort and without a host round trip;
-//   * the backward never uses global atomics: each tile writes one partial-gradient record per (Gaussian,tile)
-//     pair after a wave64 DPP reduction + fixed-order cross-wave sum, and the per-Gaussian kernel gathers its
-//     pairs in fixed order.  Gradients are bit-reproducible run to run.
+//   * V views of the same Gaussians go through one set of launches (the view is part of every work item);
+//   * binning is count (LDS tile histogram per workgroup, one global atomic per touched tile, the rank of every pair
+//     remembered) -> per-view tile scan -> atomic-free scatter -> per-tile sort on the 64-bit key
+//     (depth bits << 32 | Gaussian index).  That reproduces upstream's order (stable radix sort on tile|depth of
+//     pairs emitted in index order) without a global sort and without a host round trip;
+//   * tiles are processed in descending list length (work items built on the device), which balances the 8 XCDs;
+//   * the backward never uses global atomics: each tile writes one raw-moment record per (Gaussian,tile) pair after a
+//     wave64 transpose-reduce + fixed-order cross-wave sum, and the per-Gaussian kernel gathers its pairs in fixed
+//     order.  Gradients are bit-reproducible run to run.
 //
 // Kernels (DESIGN.md has the bytes/roofline of each):
 //   k_preprocess      A.1  per (view,Gaussian): cull, project, cov3D, EWA cov2D, conic, radius, tile rect, SH colour;
-//                          + per-tile counts (atomics) + pair-slot allocation (one returning atomic per workgroup)
-//   k_scan_tiles      A.2  per view: exclusive scan of tile counts -> tile offsets, overflow status
-//   k_scatter         A.2  per (view,Gaussian): emit key into each touched tile's bin
-//   k_sort_tiles      A.2  per (view,tile): sort the bin by (depth bits, index)
-//   k_render_fwd      A.3  per (view,tile): 256 threads = 4 wave64, each wave an 8x8 pixel block; front-to-back blend
-//   k_render_bwd      A.4  per (view,tile): back-to-front replay, wave64 reduction, one record per pair
+//                          + per-tile counts and pair ranks + pair-slot allocation (one returning atomic per workgroup)
+//   k_scan_tiles      A.2  per view: exclusive scan of tile counts -> tile offsets, overflow status, length buckets
+//   k_scatter         A.2  per (view,Gaussian): key -> tile_off + rank (no atomics); tail blocks build the work items
+//   k_sort_tiles      A.2  per work item: sort the bin by (depth bits, index): rank sort / LDS bitonic / global bitonic
+//   k_render_fwd      A.3  per work item: 256 threads = 4 wave64, each wave an 8x8 pixel block; front-to-back blend
+//   k_render_bwd      A.4  per work item: back-to-front replay, wave64 transpose-reduce, one record per pair
 //   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D/SH chain rule
+//   k_view_dot_*, k_mark_visible: small utilities of the ABI
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
