@@ -515,9 +515,11 @@ __device__ __forceinline__ void load_tile_order(const KP &kp, TileOrder &o)
 __device__ __forceinline__ uint32_t tile_order_id(const KP &kp, const TileOrder &o, const uint32_t b)
 {
     int k = 0;
+    uint32_t base = 0;
 #pragma unroll
-    for (int i = 1; i < kBuckets; i++) k += b >= o.pre[i] ? 1 : 0;
-    return kp.order[(size_t)k * kp.V * kp.T + (b - o.pre[k])];      // (view << 20) | tile
+    for (int i = 1; i < kBuckets; i++)                               // static indices only: pre[] must stay in registers
+        if (b >= o.pre[i]) { k = i; base = o.pre[i]; }
+    return kp.order[(size_t)k * kp.V * kp.T + (b - base)];           // (view << 20) | tile
 }
 
 __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
