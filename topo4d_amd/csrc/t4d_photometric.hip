@@ -25,10 +25,19 @@ int t4d_internal_fail(int code, const char *fmt, const char *a);
 
 namespace {
 
-constexpr int kT = 16;            // tile
-constexpr int kR = 5;             // window radius (11 taps)
-constexpr int kHalo = kT + 2 * kR;   // 26
-constexpr int kLd = kHalo + 1;    // LDS row stride (bank spread)
+// One workgroup = a 64 x 16 pixel tile of one channel of one view, 256 threads.  The separable 11-tap window runs as a
+// vertical pass (each task: one column, FOUR consecutive output rows, 14 input rows read once into registers) followed by
+// a horizontal pass (each thread: one row, FOUR consecutive output columns) — a register sliding window, so an output costs
+// ~3.5 + 7 LDS reads instead of 11 + 11 x (number of filtered maps).
+#ifndef T4D_PH_TW
+#define T4D_PH_TW 64
+#endif
+constexpr int kTW = T4D_PH_TW, kTH = 16;  // tile (kTW a multiple of 4)
+constexpr int kR = 5;              // window radius (11 taps)
+constexpr int kIW = kTW + 2 * kR;  // 74
+constexpr int kIH = kTH + 2 * kR;  // 26
+constexpr int kPitch = (kIW + 2) | 1;         // row pitch (elements) of the vertically filtered maps: odd multiple keeps the
+                                   // lane->row mapping of the horizontal pass free of LDS bank conflicts
 constexpr int kBlock = 256;
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
@@ -36,7 +45,7 @@ struct PhP {
     int V, H, W, tx, ty;
     const float *im, *gt, *cam_m, *cam_c, *weight;
     float *loss, *dL_dim, *dL_dm, *dL_dc;
-    float *D;            // [3][V*3*H*W] adjoint maps
+    float4 *D;           // [V*3*H*W] adjoint maps (D1, D2, D3, -)
     float *part_loss;    // [V*3*tiles][2]  (sum |x'-y|, sum S)
     float *part_cam;     // [V*3*tiles][2]  (sum g'*(x'-c), sum g')
     float win[11];
@@ -55,64 +64,89 @@ __device__ __forceinline__ float block_sum(float v, float *s_red)
 
 __global__ __launch_bounds__(kBlock) void k_photo_stats(const PhP P)
 {
-    __shared__ float s_x[kHalo][kLd], s_y[kHalo][kLd];
-    __shared__ float s_h[5][kHalo][kT + 1];
+    __shared__ float2 s_in[kIH][kIW + 1];                // (x', gt) with halo, zero padded
+    __shared__ float4 s_v4[kTH][kPitch];                 // vertically filtered (x, y, x^2, y^2)
+    __shared__ float s_v1[kTH][kPitch];                  // vertically filtered x*y
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int vc = blockIdx.z, v = vc / 3;
-    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const size_t HW = (size_t)P.H * P.W;
     const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
     const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
-    for (int i = tid; i < kHalo * kHalo; i += kBlock) {
-        const int r = i / kHalo, c = i - r * kHalo;
+    for (int i = tid; i < kIH * kIW; i += kBlock) {
+        const int r = i / kIW, c = i - r * kIW;
         const int yy = y0 + r - kR, xx = x0 + c - kR;
         float a = 0.f, b = 0.f;                                  // zero padding (external.py:86 padding=5)
         if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
             a = em * im[(size_t)yy * P.W + xx] + cc;
             b = gt[(size_t)yy * P.W + xx];
         }
-        s_x[r][c] = a; s_y[r][c] = b;
+        s_in[r][c] = make_float2(a, b);
     }
     __syncthreads();
-    for (int i = tid; i < kHalo * kT; i += kBlock) {             // horizontal pass
-        const int r = i / kT, c = i - r * kT;
-        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+    for (int t = tid; t < kIW * (kTH / 4); t += kBlock) {        // vertical pass: column `col`, output rows r0..r0+3
+        const int run = t / kIW, col = t - run * kIW, r0 = run * 4;
+        float sx[4] = { 0, 0, 0, 0 }, sy[4] = { 0, 0, 0, 0 }, sxx[4] = { 0, 0, 0, 0 }, syy[4] = { 0, 0, 0, 0 }, sxy[4] = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float a = s_x[r][c + k], b = s_y[r][c + k], w = P.win[k];
-            sx += w * a; sy += w * b; sxx += w * (a * a); syy += w * (b * b); sxy += w * (a * b);
+        for (int k = 0; k < 14; k++) {
+            const float2 ab = s_in[r0 + k][col];
+            const float a = ab.x, b = ab.y, aa = a * a, bb = b * b, abp = a * b;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int tap = k - j;
+                if (tap >= 0 && tap < 11) {
+                    const float w = P.win[tap];
+                    sx[j] += w * a; sy[j] += w * b; sxx[j] += w * aa; syy[j] += w * bb; sxy[j] += w * abp;
+                }
+            }
         }
-        s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s_v4[r0 + j][col] = make_float4(sx[j], sy[j], sxx[j], syy[j]);
+            s_v1[r0 + j][col] = sxy[j];
+        }
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4, px = x0 + lx, py = y0 + ly;
+    // horizontal pass: lane -> row (fastest), 4 consecutive output columns per thread
+    const int row = tid & 15, c0 = (tid >> 4) * 4;
+    const bool hrun = c0 < kTW;                          // (kTW / 4) * 16 threads take part in the horizontal pass
+    float mu1[4] = { 0, 0, 0, 0 }, mu2[4] = { 0, 0, 0, 0 }, ea[4] = { 0, 0, 0, 0 }, ec[4] = { 0, 0, 0, 0 }, eb[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const float4 h4 = hrun ? s_v4[row][c0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float h1 = hrun ? s_v1[row][c0 + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int tap = k - j;
+            if (tap >= 0 && tap < 11) {
+                const float w = P.win[tap];
+                mu1[j] += w * h4.x; mu2[j] += w * h4.y; ea[j] += w * h4.z; ec[j] += w * h4.w; eb[j] += w * h1;
+            }
+        }
+    }
+    const int py = y0 + row;
+    const float N = 3.f * (float)HW;
+    const float g = -0.2f * (P.weight ? P.weight[v] : 1.f) / N;              // dL/dS
     float l1 = 0.f, ss = 0.f;
-    if (px < P.W && py < P.H) {
-        float mu1 = 0.f, mu2 = 0.f, a = 0.f, c = 0.f, b = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {                           // vertical pass
-            const float w = P.win[k];
-            mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx];
-            a += w * s_h[2][ly + k][lx]; c += w * s_h[3][ly + k][lx]; b += w * s_h[4][ly + k][lx];
+    for (int j = 0; j < 4; j++) {
+        const int px = x0 + c0 + j;
+        if (hrun && px < P.W && py < P.H) {
+            const float mu1s = mu1[j] * mu1[j], mu2s = mu2[j] * mu2[j], mu12 = mu1[j] * mu2[j];
+            const float s11 = ea[j] - mu1s, s22 = ec[j] - mu2s, s12 = eb[j] - mu12;
+            const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
+            const float inv = 1.f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            ss += S;
+            const float2 ab = s_in[row + kR][c0 + j + kR];
+            l1 += fabsf(ab.x - ab.y);
+            // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
+            const float dS_dmu1 = (2.f * mu2[j] * (A2 - A1)) * inv - S * (2.f * mu1[j] / B1 - 2.f * mu1[j] / B2);
+            const float dS_da = -S / B2;
+            const float dS_db = 2.f * A1 * inv;
+            P.D[(size_t)vc * HW + (size_t)py * P.W + px] = make_float4(g * dS_dmu1, g * dS_da, g * dS_db, 0.f);
         }
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s11 = a - mu1s, s22 = c - mu2s, s12 = b - mu12;
-        const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
-        const float inv = 1.f / (B1 * B2);
-        const float S = A1 * A2 * inv;
-        ss = S;
-        l1 = fabsf(s_x[ly + kR][lx + kR] - s_y[ly + kR][lx + kR]);
-        const float N = 3.f * (float)HW;
-        const float g = -0.2f * (P.weight ? P.weight[v] : 1.f) / N;          // dL/dS
-        // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
-        const float dS_dmu1 = (2.f * mu2 * (A2 - A1)) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
-        const float dS_da = -S / B2;
-        const float dS_db = 2.f * A1 * inv;
-        const size_t o = (size_t)vc * HW + (size_t)py * P.W + px, plane = (size_t)P.V * 3 * HW;
-        P.D[o] = g * dS_dmu1;
-        P.D[plane + o] = g * dS_da;
-        P.D[2 * plane + o] = g * dS_db;
     }
     const float tl1 = block_sum(l1, s_red);
     const float tss = block_sum(ss, s_red);
@@ -124,53 +158,72 @@ __global__ __launch_bounds__(kBlock) void k_photo_stats(const PhP P)
 
 __global__ __launch_bounds__(kBlock) void k_photo_grad(const PhP P)
 {
-    __shared__ float s_d[3][kHalo][kLd];
-    __shared__ float s_h[3][kHalo][kT + 1];
+    __shared__ float4 s_d[kIH][kIW + 1];                 // (D1, D2, D3, -) with halo
+    __shared__ float4 s_v[kTH][kPitch];                  // vertically filtered
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int vc = blockIdx.z, v = vc / 3;
-    const int x0 = blockIdx.x * kT, y0 = blockIdx.y * kT;
-    const size_t HW = (size_t)P.H * P.W, plane = (size_t)P.V * 3 * HW;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const size_t HW = (size_t)P.H * P.W;
     const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
-    for (int i = tid; i < kHalo * kHalo; i += kBlock) {
-        const int r = i / kHalo, c = i - r * kHalo;
+    for (int i = tid; i < kIH * kIW; i += kBlock) {
+        const int r = i / kIW, c = i - r * kIW;
         const int yy = y0 + r - kR, xx = x0 + c - kR;
         const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
-        const size_t o = (size_t)vc * HW + (size_t)(in ? yy : 0) * P.W + (in ? xx : 0);
-#pragma unroll
-        for (int m = 0; m < 3; m++) s_d[m][r][c] = in ? P.D[m * plane + o] : 0.f;
+        s_d[r][c] = in ? P.D[(size_t)vc * HW + (size_t)yy * P.W + xx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    for (int i = tid; i < kHalo * kT; i += kBlock) {
-        const int r = i / kT, c = i - r * kT;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = tid; t < kIW * (kTH / 4); t += kBlock) {
+        const int run = t / kIW, col = t - run * kIW, r0 = run * 4;
+        float a0[4] = { 0, 0, 0, 0 }, a1[4] = { 0, 0, 0, 0 }, a2[4] = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = P.win[k];
-            s0 += w * s_d[0][r][c + k]; s1 += w * s_d[1][r][c + k]; s2 += w * s_d[2][r][c + k];
+        for (int k = 0; k < 14; k++) {
+            const float4 d4 = s_d[r0 + k][col];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int tap = k - j;
+                if (tap >= 0 && tap < 11) {
+                    const float w = P.win[tap];
+                    a0[j] += w * d4.x; a1[j] += w * d4.y; a2[j] += w * d4.z;
+                }
+            }
         }
-        s_h[0][r][c] = s0; s_h[1][r][c] = s1; s_h[2][r][c] = s2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) s_v[r0 + j][col] = make_float4(a0[j], a1[j], a2[j], 0.f);
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4, px = x0 + lx, py = y0 + ly;
+    const int row = tid & 15, c0 = (tid >> 4) * 4;
+    const bool hrun = c0 < kTW;
+    float q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 }, q2[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const float4 h4 = hrun ? s_v[row][c0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int tap = k - j;
+            if (tap >= 0 && tap < 11) {
+                const float w = P.win[tap];
+                q0[j] += w * h4.x; q1[j] += w * h4.y; q2[j] += w * h4.z;
+            }
+        }
+    }
+    const int py = y0 + row;
+    const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
     float gm = 0.f, gc = 0.f;
-    if (px < P.W && py < P.H) {
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = P.win[k];
-            c0 += w * s_h[0][ly + k][lx]; c1 += w * s_h[1][ly + k][lx]; c2 += w * s_h[2][ly + k][lx];
+    for (int j = 0; j < 4; j++) {
+        const int px = x0 + c0 + j;
+        if (hrun && px < P.W && py < P.H) {
+            const size_t o = (size_t)vc * HW + (size_t)py * P.W + px;
+            const float imv = P.im[o], y = P.gt[o];
+            const float x = em * imv + cc;
+            const float d = x - y;
+            const float gl1 = 0.8f * wv / N * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            const float g = q0[j] + 2.f * x * q1[j] + y * q2[j] + gl1;         // dL/dx'
+            P.dL_dim[o] = em * g;
+            gm += g * (em * imv);                                               // d x'/d cam_m = exp(cam_m) * im
+            gc += g;
         }
-        const size_t o = (size_t)vc * HW + (size_t)py * P.W + px;
-        const float imv = P.im[o], y = P.gt[o];
-        const float x = em * imv + cc;
-        const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
-        const float d = x - y;
-        const float gl1 = 0.8f * wv / N * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        const float g = c0 + 2.f * x * c1 + y * c2 + gl1;         // dL/dx'
-        P.dL_dim[o] = em * g;
-        gm = g * (em * imv);                                      // d x'/d cam_m = exp(cam_m) * im
-        gc = g;
     }
     const float tgm = block_sum(gm, s_red);
     const float tgc = block_sum(gc, s_red);
@@ -215,8 +268,8 @@ T4D_EXPORT size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int3
 {
     if (n_views < 1 || H < 1 || W < 1) return 0;
     const size_t n = (size_t)n_views * 3 * H * W;
-    const size_t tiles = (size_t)((W + kT - 1) / kT) * ((H + kT - 1) / kT) * n_views * 3;
-    return align_up(3 * n * 4) + 2 * align_up(tiles * 8);
+    const size_t tiles = (size_t)((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) * n_views * 3;
+    return align_up(n * 16) + 2 * align_up(tiles * 8);
 }
 
 T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *cam_m,
@@ -233,14 +286,14 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     PhP P;
     memset(&P, 0, sizeof(P));
     P.V = n_views; P.H = H; P.W = W;
-    P.tx = (W + kT - 1) / kT; P.ty = (H + kT - 1) / kT;
+    P.tx = (W + kTW - 1) / kTW; P.ty = (H + kTH - 1) / kTH;
     P.im = im; P.gt = gt; P.cam_m = cam_m; P.cam_c = cam_c; P.weight = view_weight;
     P.loss = loss; P.dL_dim = dL_dim; P.dL_dm = dL_dcam_m; P.dL_dc = dL_dcam_c;
     const size_t n = (size_t)n_views * 3 * H * W, tiles = (size_t)P.tx * P.ty * n_views * 3;
     char *sc = (char *)scratch;
-    P.D = (float *)sc;
-    P.part_loss = (float *)(sc + align_up(3 * n * 4));
-    P.part_cam = (float *)(sc + align_up(3 * n * 4) + align_up(tiles * 8));
+    P.D = (float4 *)sc;
+    P.part_loss = (float *)(sc + align_up(n * 16));
+    P.part_cam = (float *)(sc + align_up(n * 16) + align_up(tiles * 8));
     // the reference's window: exp(-(i-5)^2 / (2*1.5^2)) for i = 0..10, as float32, normalised in float32 (external.py:73-76)
     float g[11], sum = 0.f;
     for (int i = 0; i < 11; i++) { g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
