@@ -58,7 +58,10 @@ enum {
     T4D_FLAG_CHECKED = 1u,     /* forward: sync once after binning sizes are known and fail with PAIR_OVERFLOW
                                   instead of rendering truncated tile lists (what upstream's num_rendered D2H does) */
     T4D_FLAG_DEBUG_SYNC = 2u,  /* `debug=True` of the settings tuple: synchronise + check after every kernel */
-    T4D_FLAG_PREFILTERED = 4u  /* accepted for API parity (helpers.py:84 passes False); no effect */
+    T4D_FLAG_PREFILTERED = 4u, /* accepted for API parity (helpers.py:84 passes False); no effect */
+    T4D_FLAG_ASYNC_STATUS = 8u /* forward, without CHECKED: `status` must point at PINNED host memory; the first 16 bytes
+                                  receive { uint32 overflow; uint32 max_pairs_per_view; uint64 total_pairs } by an
+                                  asynchronous copy enqueued behind the binning kernels — no host synchronisation */
 };
 
 typedef struct T4DProblem {

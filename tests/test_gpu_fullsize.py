@@ -229,3 +229,55 @@ def test_module_accepts_what_upstream_accepts():
     out[0].sum().backward()
     assert cov.grad is not None and torch.isfinite(cov.grad).all() and cov.grad.abs().max() > 0
     assert R.markVisible(base["means3D"]).all()
+
+
+def test_auto_sync_mode_tracks_capacity_without_syncing():
+    import topo4d_amd
+    from topo4d_amd import rasterizer, scene
+    H = W = 96
+    rv, cams = util.make_scene(20, 32, H, W, 2, opacity="B", seed=4)
+    dcams = util.to_device(cams, "cuda")
+    d = {k: v.cuda() for k, v in rv.items()}
+    R = [topo4d_amd.GaussianRasterizer(c) for c in dcams]
+    call = lambda r, sc=1.0: r(d["means3D"], None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * sc,
+                               rotations=d["rotations"])
+    ref = [[t.clone() for t in call(r)] for r in R]
+    rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear()
+    topo4d_amd.set_sync_mode("auto")
+    try:
+        for it in range(4):                                   # first call per camera is checked, the rest are not
+            for k, r in enumerate(R):
+                out = call(r)
+                for a, b in zip(out, ref[k]):
+                    assert torch.equal(a, b)
+        tracks = list(rasterizer._AUTO.values())
+        assert len(tracks) == 2 and all(t.need > 0 for t in tracks)
+        # a slowly growing scene (scales +8 % per iteration): capacity follows, nothing is ever truncated
+        sc = 1.0
+        for it in range(12):
+            sc *= 1.08
+            out = call(R[0], sc)
+            topo4d_amd.set_sync_mode("checked"); chk = call(R[0], sc); topo4d_amd.set_sync_mode("auto")
+            for a, b in zip(out, chk):
+                assert torch.equal(a, b)
+        # same with the host running ahead of the GPU (no synchronisation at all for 30 forwards)
+        for it in range(30):
+            sc *= 1.03
+            out = call(R[1], sc)
+        topo4d_amd.set_sync_mode("checked"); chk = call(R[1], sc); topo4d_amd.set_sync_mode("auto")
+        for a, b in zip(out, chk):
+            assert torch.equal(a, b)
+        # an abrupt jump (scales x6 from one call to the next) overflows once and is REPORTED at the following call
+        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear()
+        call(R[0]); call(R[0])
+        call(R[0], 6.0)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="truncated"):
+            call(R[0], 6.0)
+        out = call(R[0], 6.0)                                  # arena was enlarged: now complete again
+        topo4d_amd.set_sync_mode("checked")
+        for a, b in zip(out, call(R[0], 6.0)):
+            assert torch.equal(a, b)
+    finally:
+        topo4d_amd.set_sync_mode("checked")
+        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear()

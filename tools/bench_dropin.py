@@ -51,7 +51,7 @@ def it_torch_all(i):
             params["means3D"][static_idx] = static_vals
 
 out = {"workload": "1 view per call, P=8280, 512x375, opacity 1.0 (Topo4D geometry pass shape)"}
-for mode in ("checked", "lazy"):
+for mode in ("checked", "auto", "lazy"):
     topo4d_amd.set_sync_mode("checked")
     for name, fn in (("raster_only", it_raster), ("iter_torch_loss", it_torch_loss), ("iter_fused_loss", it_fused_loss),
                      ("iter_torch_loss_adam_freezes", it_torch_all), ("iter_fused_loss_adam_pins", it_fused_all)):

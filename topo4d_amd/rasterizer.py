@@ -50,6 +50,47 @@ class GaussianRasterizationSettings(NamedTuple):
 # ------------------------------------------------------------------------------------------------------------
 _SYNC_MODE = "checked"
 _CAPACITY = {}          # (device_index, P, H, W) -> learned per-view pair capacity
+_AUTO = {}              # (device_index, P, H, W, views key) -> _AutoTrack of the "auto" sync mode
+
+
+class _AutoTrack:
+    """Bookkeeping of the "auto" sync mode for one (scene size, camera set): a ring of pinned status blocks, one per
+    un-synchronised forward still in flight, each with the event that says it has landed, and the largest need seen."""
+    RING = 8
+    __slots__ = ("pinned", "host", "events", "caps", "head", "count", "need")
+
+    def __init__(self):
+        self.pinned = torch.zeros(self.RING, 2, dtype=torch.int64).pin_memory()
+        self.host = self.pinned.numpy()                 # same memory, cheap scalar reads
+        self.events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.caps = [0] * self.RING
+        self.head = 0                                   # next slot to hand out
+        self.count = 0                                  # slots in flight (oldest = head - count)
+        self.need = 0
+
+    def slot_ptr(self) -> int:
+        return self.pinned.data_ptr() + 16 * self.head
+
+    def mark(self, stream, cap):
+        self.events[self.head].record(stream)
+        self.caps[self.head] = cap
+        self.head = (self.head + 1) % self.RING
+        self.count += 1
+
+    def harvest(self):
+        """Yields (overflow, need, capacity used) of every un-synchronised call whose status has landed, oldest first.
+        Waits for the oldest one only when the ring is full (the host is then RING forwards ahead of the GPU)."""
+        out = []
+        while self.count:
+            tail = (self.head - self.count) % self.RING
+            if self.count == self.RING:
+                self.events[tail].synchronize()
+            elif not self.events[tail].query():
+                break
+            raw = int(self.host[tail, 0])
+            out.append((raw & 0xffffffff, (raw >> 32) & 0xffffffff, self.caps[tail]))
+            self.count -= 1
+        return out
 
 
 def set_sync_mode(mode: str) -> None:
@@ -57,10 +98,15 @@ def set_sync_mode(mode: str) -> None:
     with a larger pair arena if it was too small — exactly where upstream reads `num_rendered` back.
     "lazy": never synchronises; tile lists are truncated (memory-safe) if the arena learned by earlier checked
     calls is too small, and `ViewBatch.fetch_status()` / `last_status()` reports it.  Use lazy only when the
-    capacity was established by a checked call on (nearly) the same scene — bench.py does."""
+    capacity was established by a checked call on (nearly) the same scene — bench.py does.
+    "auto": for optimisation loops.  The first forward of every (scene size, camera set) is checked; afterwards the
+    forward does not synchronise, the binning status is copied to pinned host memory asynchronously and inspected at a
+    later call with the same cameras (the next one if the GPU keeps up, at most 8 calls later if the host runs ahead): the arena is grown as soon as 75 % of it is in use (it is sized 1.5x the largest need
+    seen), so consecutive iterations of an optimiser cannot overflow it; should a previous call nevertheless have been
+    truncated (the scene jumped by more than a third between two calls), a RuntimeError says so."""
     global _SYNC_MODE
-    if mode not in ("checked", "lazy"):
-        raise ValueError("sync mode must be 'checked' or 'lazy'")
+    if mode not in ("checked", "lazy", "auto"):
+        raise ValueError("sync mode must be 'checked', 'lazy' or 'auto'")
     _SYNC_MODE = mode
 
 
@@ -153,7 +199,7 @@ class ViewBatch:
     """
 
     def __init__(self, views: torch.Tensor, H: int, W: int, scale_modifier: float = 1.0, sh_degree: int = 0,
-                 debug: bool = False, prefiltered: bool = False):
+                 debug: bool = False, prefiltered: bool = False, cam_key=None):
         if not views.is_cuda:
             raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
         self.lib = _lib.load()
@@ -165,6 +211,7 @@ class ViewBatch:
         self.debug = bool(debug)
         self.prefiltered = bool(prefiltered)
         self.device = views.device
+        self.cam_key = cam_key if cam_key is not None else (views.data_ptr(), self.V)   # identity of the camera set ("auto" mode)
         self.state = None
         self.prob = None
         self.inputs = None
@@ -222,15 +269,42 @@ class ViewBatch:
         key = (dev.index, P, H, W)
         cap = _CAPACITY.get(key, _initial_capacity(P))
         checked = (_SYNC_MODE == "checked") or self.debug or key not in _CAPACITY
+        track = None
+        if _SYNC_MODE == "auto" and not self.debug:
+            akey = key + (self.cam_key,)
+            track = _AUTO.get(akey)
+            if track is None:
+                track = _AUTO[akey] = _AutoTrack()
+                checked = True                                    # first time these cameras see this scene size
+            else:
+                truncated = None
+                for overflow, need, cap_used in track.harvest():
+                    track.need = max(track.need, need)
+                    if overflow:
+                        truncated = (need, cap_used)
+                if truncated is not None:
+                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), _round_capacity(track.need))
+                    raise RuntimeError(
+                        f"topo4d_amd (sync_mode='auto'): an earlier render of these cameras needed {truncated[0]} "
+                        f"(Gaussian,tile) pairs per view but its arena held {truncated[1]}; it was truncated. The arena has been "
+                        "enlarged; re-run that iteration, or use set_sync_mode('checked') for scenes that change abruptly.")
+                if track.need > 0.75 * cap:                       # grow well before the arena can overflow
+                    cap = _round_capacity(track.need)
+                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), cap)
+                cap = _CAPACITY.get(key, cap)
         status = T4DStatus()
         for _attempt in range(6):
             prob = self._problem(P, M, cap, checked)
+            status_arg = C.byref(status)
+            if track is not None and not checked:
+                prob.flags |= _lib.T4D_FLAG_ASYNC_STATUS
+                status_arg = C.cast(C.c_void_p(track.slot_ptr()), C.POINTER(T4DStatus))
             nbytes = self.lib.t4d_state_bytes(C.byref(prob))
             state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             io = T4DForwardIO(_ptr(self.views), _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations),
                               _ptr(cov3D_precomp), _ptr(colors_precomp), _ptr(shs), _ptr(color), _ptr(depth),
                               _ptr(alpha), _ptr(radii), _ptr(state), nbytes)
-            rc = self.lib.t4d_rasterize_forward(C.byref(prob), C.byref(io), C.byref(status), self._stream())
+            rc = self.lib.t4d_rasterize_forward(C.byref(prob), C.byref(io), status_arg, self._stream())
             if rc == T4D_OK:
                 break
             if rc == T4D_ERR_PAIR_OVERFLOW:
@@ -243,6 +317,10 @@ class ViewBatch:
             # keep 1.5x head-room over what this scene needs so that lazy calls on nearby scenes fit
             want = _round_capacity(status.max_pairs_per_view)
             _CAPACITY[key] = max(want, cap if key in _CAPACITY else 0)
+            if track is not None:
+                track.need = max(track.need, int(status.max_pairs_per_view))
+        elif track is not None:
+            track.mark(torch.cuda.current_stream(dev), cap)
         self.prob, self.state, self.radii = prob, state, radii
         self.inputs = (means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs)
         self.last_status = status if checked else None
@@ -320,8 +398,8 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                views, H, W, scale_modifier, sh_degree, debug, prefiltered):
-        batch = ViewBatch(views, H, W, scale_modifier, sh_degree, debug, prefiltered)
+                views, H, W, scale_modifier, sh_degree, debug, prefiltered, cam_key=None):
+        batch = ViewBatch(views, H, W, scale_modifier, sh_degree, debug, prefiltered, cam_key)
         none_if_empty = lambda t: None if (t is None or t.numel() == 0) else t
         color, radii, depth, alpha = batch.forward(
             means3D, opacities, none_if_empty(scales), none_if_empty(rotations), none_if_empty(colors_precomp),
@@ -353,7 +431,7 @@ class _RasterizeViews(torch.autograd.Function):
             red(g["scales"]),
             red(g["rotations"]),
             red(g["cov3D_precomp"]),
-            None, None, None, None, None, None, None,
+            None, None, None, None, None, None, None, None,
         )
         ctx.batch = None
         return grads
@@ -375,8 +453,9 @@ def rasterize_views(settings: Sequence[GaussianRasterizationSettings], means3D, 
     nz = lambda t: empty if t is None else t
     debug = any(bool(s.debug) for s in settings)
     pref = any(bool(s.prefiltered) for s in settings)
+    cam_key = tuple(id(s_) for s_ in settings)           # Settings tuples are built once per camera per frame (train.py:98)
     return _RasterizeViews.apply(means3D, means2D, nz(shs), nz(colors_precomp), opacities, nz(scales),
-                                 nz(rotations), nz(cov3D_precomp), views, H, W, smod, deg, debug, pref)
+                                 nz(rotations), nz(cov3D_precomp), views, H, W, smod, deg, debug, pref, cam_key)
 
 
 class GaussianRasterizer(nn.Module):
