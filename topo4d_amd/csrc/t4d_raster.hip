@@ -715,19 +715,23 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 
 // ---------------------------------------------------------------------------------------------------------
 // A.3 / A.4 shared pieces.
-// Workgroup = 16x16 tile; wave w owns the 8x8 pixel block (w&1, w>>1); lane l the pixel (l&7, l>>3).
-// Per staged splat one lane computes, for each of the 4 blocks, a CONSERVATIVE test "can alpha reach 1/255 on any
-// pixel centre of the block?"; the four wave64 ballots become per-block bit masks and every wave only visits
-// the set bits of its own mask (s_ff1 / s_flbit on an SGPR pair).  Skipped splats would have been rejected by
-// the per-pixel alpha < 1/255 test anyway, so results are unchanged.
+// Workgroup = 16x16 tile; wave w owns the 8x8 pixel block (w&1, w>>1); inside it DPP row r (16 lanes) owns the 4x4
+// sub-block (r&1, r>>1) and lane i of the row the pixel (i&3, i>>2).  The four rows of a wave walk FOUR DIFFERENT visit
+// lists at the same time (one per sub-block): a splat of Topo4D's size (cut-off radius ~5 px) touches a 4x4 sub-block
+// 1.6x less often than an 8x8 block, so a wave needs that many fewer steps, every lane still sees its splats in list
+// order (results are bit-identical to a per-pixel walk), and the backward's per-splat reduction runs over 16 lanes with
+// row-local DPP only, for four splats at once.
+// Per staged splat one lane computes, for each of the 16 sub-blocks, a CONSERVATIVE test "can alpha reach 1/255 on any
+// pixel centre of the sub-block?"; the wave64 ballots become per-sub-block bit masks.  Skipped splats would have been
+// rejected by the per-pixel alpha < 1/255 test anyway, so results are unchanged.
 // ---------------------------------------------------------------------------------------------------------
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ void tile_pixel(int tid, int tx, int ty, int &px, int &py)
 {
-    const int w = tid >> 6, l = tid & 63;
-    px = tx * T4D_TILE_X + ((w & 1) << 3) + (l & 7);
-    py = ty * T4D_TILE_Y + ((w >> 1) << 3) + (l >> 3);
+    const int w = tid >> 6, r = (tid >> 4) & 3, i = tid & 15;
+    px = tx * T4D_TILE_X + ((w & 1) << 3) + ((r & 1) << 2) + (i & 3);
+    py = ty * T4D_TILE_Y + ((w >> 1) << 3) + ((r >> 1) << 2) + (i >> 2);
 }
 
 // squared cut-off radius (pixels) beyond which opacity * exp(power) < 1/255 with margin; +inf = "cannot cull"
@@ -743,19 +747,29 @@ __device__ __forceinline__ float cutoff_radius2(const float4 co)
     return 2.0f * (lnarg + 2e-3f) / lmin * 1.001f;
 }
 
-// bit w set <=> the splat centred at p with cut-off r2 can touch 8x8 block w of tile (tx,ty)
-__device__ __forceinline__ uint32_t block_touch_mask(const float2 p, const float r2, const int tx, const int ty)
+// bit (4*w + r) set <=> the splat centred at p with cut-off r2 can touch 4x4 sub-block r of wave w of tile (tx,ty)
+__device__ __forceinline__ uint32_t subblock_touch_mask(const float2 p, const float r2, const int tx, const int ty)
 {
+    float dx2[4], dy2[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float x0 = (float)(tx * T4D_TILE_X + 4 * c), y0 = (float)(ty * T4D_TILE_Y + 4 * c);
+        const float ddx = fmaxf(fmaxf(x0 - p.x, p.x - (x0 + 3.f)), 0.f);
+        const float ddy = fmaxf(fmaxf(y0 - p.y, p.y - (y0 + 3.f)), 0.f);
+        dx2[c] = ddx * ddx; dy2[c] = ddy * ddy;
+    }
     uint32_t m = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const float bx0 = (float)(tx * T4D_TILE_X + ((w & 1) << 3)), by0 = (float)(ty * T4D_TILE_Y + ((w >> 1) << 3));
-        const float ddx = fmaxf(fmaxf(bx0 - p.x, p.x - (bx0 + 7.f)), 0.f);
-        const float ddy = fmaxf(fmaxf(by0 - p.y, p.y - (by0 + 7.f)), 0.f);
-        if (!(ddx * ddx + ddy * ddy > r2)) m |= 1u << w;
+    for (int sb = 0; sb < 16; sb++) {
+        const int w = sb >> 2, r = sb & 3;
+        const int cx = ((w & 1) << 1) | (r & 1), cy = ((w >> 1) << 1) | (r >> 1);
+        if (!(dx2[cx] + dy2[cy] > r2)) m |= 1u << sb;
     }
     return m;
 }
+
+// SGPR copy of lane `src_lane`'s value
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
 // The ONE place alpha is evaluated, shared by forward and backward so that both take bit-identical decisions.
 // q = (A, B, C) * log2(e) pre-multiplied by (-0.5, -1, -0.5); returns p2 = power * log2(e), G = exp(power).
@@ -810,13 +824,15 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
     constexpr int kNull = kFwdBatch;                 // staged slot that can never contribute (opacity 0)
+    constexpr int kChunks = kFwdBatch / 64;
+    constexpr int kListStride = kFwdBatch + 4;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
     __shared__ float2 s_xy[kFwdBatch + 1];
     __shared__ float4 s_q[kFwdBatch + 1];            // scaled conic + opacity
     __shared__ float4 s_cd[kFwdBatch + 1];           // rgb + depth
-    __shared__ unsigned long long s_mask[4][kFwdBatch / 64];
-    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][kFwdBatch + 4];
+    __shared__ unsigned long long s_mask[16][kChunks];
+    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
     if (tid == 0) {
         s_xy[kNull] = make_float2(0.f, 0.f);
         s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -855,32 +871,39 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 s_q[tid] = scale_conic(c);
                 s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
                                         __uint_as_float((uint32_t)(key >> 32)));
-                touch = block_touch_mask(p, cutoff_radius2(c), tx, ty);
+                touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
             }
         }
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const unsigned long long bal = __ballot((touch >> w) & 1u);
-            if (lane == 0) s_mask[w][wave] = bal;
+        for (int sb = 0; sb < 16; sb++) {
+            const unsigned long long bal = __ballot((touch >> sb) & 1u);
+            if (lane == sb) s_mask[sb][wave] = bal;
         }
         __syncthreads();
         if (__all(done)) continue;                   // wave-uniform; still takes part in the barriers above
-        unsigned long long m[kFwdBatch / 64];
+        int nsteps = 0, my_cnt = 0;
 #pragma unroll
-        for (int c4 = 0; c4 < kFwdBatch / 64; c4++) m[c4] = uniform_u64(s_mask[wave][c4]);
-        unsigned short *list = s_list[wave];
-        int cnt = build_visit_list<kFwdBatch / 64, false>(m, list, lane, (unsigned short)kNull);
+        for (int r = 0; r < 4; r++) {                // one visit list per 4x4 sub-block (= DPP row) of this wave
+            unsigned long long m[kChunks];
+#pragma unroll
+            for (int c4 = 0; c4 < kChunks; c4++) m[c4] = uniform_u64(s_mask[wave * 4 + r][c4]);
+            const int cnt = build_visit_list<kChunks, false>(m, s_list[wave][r], lane, (unsigned short)kNull);
+            nsteps = max(nsteps, cnt);
+            my_cnt = row == r ? cnt : my_cnt;
+        }
+        const unsigned short *list = s_list[wave][row];
 #if T4D_ABL == 5
-        cnt = 0;
+        nsteps = 0;
 #endif
-        for (int k = 0; k < cnt; k += 4) {
+        for (int k = 0; k < nsteps; k += 4) {
             const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
-            const int j[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
+            int j[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
             float alpha[4];
             bool valid[4];
             bool anyv = false;
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // four independent evaluations: ILP hides LDS / exp latency
+                j[u] = k + u < my_cnt ? j[u] : kNull;    // rows with shorter lists idle on the null splat
                 const float2 g_xy = s_xy[j[u]];
                 float p2, G;
                 eval_splat(s_q[j[u]], g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha[u]);
@@ -928,97 +951,109 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// wave64 reduction of TEN values at once ("transpose-reduce"): at every butterfly level two partial-sum vectors
-// are folded into one, each half of the lanes keeping a different value, so the work halves per level instead of
-// staying at 10 adds x 6 levels.  Levels: xor32 / xor16 by v_permlane{32,16}_swap (gfx950), xor8 by row_ror:8,
-// xor4 by two bank-masked row shifts, xor2 / xor1 by quad_perm.  27 VALU instead of 60.
-// On return lane L (L % 4 == 0) holds the wave-wide sum of value red10_index(L) (or garbage when that is < 0).
+// Reduction of TEN values over each 16-lane DPP row ("transpose-reduce"): at every butterfly level two partial-sum
+// vectors are folded into one, each half of the lanes keeping a different value, so the work halves per level
+// instead of staying at 10 adds x 4 levels.  Levels: xor8 by row_ror:8, xor4 by two bank-masked row shifts, xor2 /
+// xor1 by quad_perm.  The four rows of a wave reduce four different splats at the same time.
+// On return lane i of a row holds the row-wide sum of value row10_index(i) (or garbage when that is < 0).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float swap32_add(float a, float b)
+// In-place butterfly over ten VGPRs, written as one asm block: bank-masked DPP adds do the "keep one half, send the
+// other" selection of the transpose for free (v_cndmask + v_mov_dpp pairs otherwise), and the instruction order keeps
+// every DPP read at least two instructions behind the write of its source (the gfx9 VALU->DPP hazard), so no s_nop is
+// needed inside; the leading s_nop covers inputs produced just before the block.
+//   level xor8 (row_ror:8):  r[2m] <- r[2m + b3] summed over the pair          (banks 2,3 = lanes with b3 set)
+//   level xor4 (row_shl/shr:4): r1 <- c_{b2}, r3 <- c_{2+b2}, r5 <- c_4        (banks 0,2 read lane+4; banks 1,3 lane-4)
+//   levels xor2, xor1 (quad_perm): plain butterflies on r1, r3, r5
+// On return, in lane i = (b3 b2 b1 b0) of a row:  r1 = sum of value 2*b2 + b3,  r3 = sum of value 4 + 2*b2 + b3,
+// r5 = sum of value 8 + b3.
+__device__ __forceinline__ void reduce10_row(float (&r)[10])
 {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
 }
 
-__device__ __forceinline__ float swap16_add(float a, float b)
+// which of the ten sums lane i of a row keeps after reduce10_row (taken from r1 / r3 / r5 by (b1 b0)); -1 = none
+__device__ __forceinline__ int row10_index(const int lane)
 {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+    if (!b1 && !b0) return 2 * b2 + b3;
+    if (!b1 && b0) return 4 + 2 * b2 + b3;
+    if (b1 && !b0 && !b2) return 8 + b3;
+    return -1;
 }
 
-template <int CTRL, int BANK_MASK = 0xf>
-__device__ __forceinline__ float dppz(float old, float v)
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane gets the maximum over its 16-lane row
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANK_MASK, true));
-}
-
-__device__ __forceinline__ float reduce10(const float r[10], const int lane)
-{
-    // level xor32: lanes <32 keep the even member of each pair, lanes >=32 the odd one
-    const float s0 = swap32_add(r[0], r[1]), s1 = swap32_add(r[2], r[3]), s2 = swap32_add(r[4], r[5]);
-    const float s3 = swap32_add(r[6], r[7]), s4 = swap32_add(r[8], r[9]);
-    // level xor16: even rows keep the first member, odd rows the second
-    const float t0 = swap16_add(s0, s1), t1 = swap16_add(s2, s3), t2 = swap16_add(s4, 0.f);
-    // level xor8 (row_ror:8)
-    const bool b3 = (lane & 8) != 0;
-    const float keep8 = b3 ? t1 : t0, send8 = b3 ? t0 : t1;
-    const float u0 = keep8 + dppz<0x128>(0.f, send8);
-    const float u1 = t2 + dppz<0x128>(0.f, t2);
-    // level xor4: banks {0,2} read lane+4 (row_shl:4), banks {1,3} read lane-4 (row_shr:4)
-    const bool b2 = (lane & 4) != 0;
-    const float keep4 = b2 ? u1 : u0, send4 = b2 ? u0 : u1;
-    float recv = dppz<0x104, 0x5>(0.f, send4);
-    recv = dppz<0x114, 0xA>(recv, send4);
-    float w = keep4 + recv;
-    // levels xor1, xor2 inside each quad
-    w += dppz<0xB1>(0.f, w);
-    w += dppz<0x4E>(0.f, w);
-    return w;
-}
-
-// which of the ten values lane L (L % 4 == 0) holds after reduce10; -1 = none
-__device__ __forceinline__ int red10_index(const int lane)
-{
-    const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
-    if (lane & 3) return -1;
-    if (b2) return (b3 || b4) ? -1 : 8 + b5;
-    return 4 * b3 + 2 * b4 + b5;
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // A.4 backward replay.  No global atomics: one kGP-float record per (Gaussian,tile) pair.
 // record (raw sums over the tile's pixels, e = G * dL/dalpha, d = splat centre - pixel):
 //   [0] sum e   [1,2] sum e*d   [3,4,5] sum e*dx*dx, e*dx*dy, e*dy*dy   [6,7,8] sum alpha*T*dL/dC   [9] sum alpha*T*dL/dD
+// Inside the workgroup every wave owns an LDS slab of ten sums per staged splat; a row's reduced sums are added to it
+// with ds_add_f32 (at most four lanes - the wave's four rows - ever hit one address, in one instruction, so the order
+// of the additions is fixed), and the slabs of the four waves are summed in wave order when the batch is written out.
 // ---------------------------------------------------------------------------------------------------------
 // DA = the caller supplied dL/ddepth and/or dL/dalpha.  Topo4D discards depth and alpha (train.py:307), so its backward
 // runs the DA = false instantiation, which carries neither the two extra suffix accumulators nor their products.
-// 5 waves per SIMD (96 VGPRs, 6 dwords of scratch) measured 7 % faster than the compiler's own choice of 107 VGPRs /
-// 4 waves: the kernel is latency-bound between dependent DPP/LDS steps, so the extra resident wave pays for the spill.
 #ifndef T4D_BWD_WAVES
 #define T4D_BWD_WAVES 5
 #endif
 #define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(T4D_BWD_WAVES, T4D_BWD_WAVES)))
+constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
 template <bool DA>
 __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
+    constexpr int kChunks = kBwdBatch / 64;
+    constexpr int kListStride = kBwdBatch + 4;
     __shared__ float2 s_xy[kBwdBatch + 1];
     __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
-    __shared__ float4 s_cd[kBwdBatch];
+    __shared__ float4 s_cd[kBwdBatch + 1];
     __shared__ uint32_t s_pair[kBwdBatch];
-    __shared__ float s_acc[4][kBwdBatch][kGP];
-    __shared__ unsigned long long s_mask[4][kBwdBatch / 64];   // cull masks (in), then "slab written" masks (out)
+    __shared__ __attribute__((aligned(8))) float s_acc[4][kBwdBatch][kAcc];
+    __shared__ unsigned long long s_mask[16][kChunks];
     __shared__ uint32_t s_wmax[4];
-    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][kBwdBatch + 4];
+    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     constexpr int kNull = kBwdBatch;
-    static_assert(kBwdBatch == 64 || kBwdBatch == 128, "the slab-written masks below assume one or two 64-splat chunks per batch");
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int my_slot = red10_index(lane);
+    const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
+    const int my_slot = row10_index(lane & 15);
+    const bool sel_mid = (lane & 3) == 1, sel_hi = (lane & 3) == 2;
     if (tid == 0) {
         s_xy[kNull] = make_float2(0.f, 0.f);
         s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_cd[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    for (int i = tid; i < 4 * kBwdBatch * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
     for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {
     const uint4 it = kp.items[item];
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
@@ -1057,7 +1092,11 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     float acc = 0.f, last_q = 0.f, last_alpha = 0.f;
     const float tf_bg = T_final * (vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2);
 
-    const uint32_t wave_max = wave_max_u32(last_contributor);
+    const uint32_t rmax_v = row_max_u32(last_contributor);
+    uint32_t row_max[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) row_max[r] = lane_value(rmax_v, 16 * r);
+    const uint32_t wave_max = max(max(row_max[0], row_max[1]), max(row_max[2], row_max[3]));
     if (lane == 0) s_wmax[wave] = wave_max;
     __syncthreads();
     const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
@@ -1084,43 +1123,48 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                 s_q[tid] = scale_conic(c);
                 s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
                                         __uint_as_float((uint32_t)(key >> 32)));
-                touch = block_touch_mask(p, cutoff_radius2(c), tx, ty);
+                touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
             }
         }
-        if (wave < kBwdBatch / 64) {
+        if (wave < kChunks) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const unsigned long long bal = __ballot((touch >> w) & 1u);
-                if (lane == 0) s_mask[w][wave] = bal;
+            for (int sb = 0; sb < 16; sb++) {
+                const unsigned long long bal = __ballot((touch >> sb) & 1u);
+                if (lane == sb) s_mask[sb][wave] = bal;
             }
         }
         __syncthreads();
-        unsigned long long wrote[kBwdBatch / 64];
-#pragma unroll
-        for (int c2 = 0; c2 < kBwdBatch / 64; c2++) wrote[c2] = 0ull;
         if (live) {
-            unsigned long long m[kBwdBatch / 64];
+            int nsteps = 0, my_cnt = 0;
 #pragma unroll
-            for (int c2 = 0; c2 < kBwdBatch / 64; c2++) {
-                m[c2] = uniform_u64(s_mask[wave][c2]);
-                // positions at or beyond the wave's last contributor cannot matter: drop them from the mask
-                const uint32_t base = lo + ((uint32_t)c2 << 6);
-                if (wave_max <= base) m[c2] = 0;
-                else if (wave_max - base < 64u) m[c2] &= (1ull << (wave_max - base)) - 1ull;
+            for (int r = 0; r < 4; r++) {
+                unsigned long long m[kChunks];
+#pragma unroll
+                for (int c2 = 0; c2 < kChunks; c2++) {
+                    m[c2] = uniform_u64(s_mask[wave * 4 + r][c2]);
+                    // positions at or beyond the row's last contributor cannot matter: drop them from the mask
+                    const uint32_t base = lo + ((uint32_t)c2 << 6);
+                    if (row_max[r] <= base) m[c2] = 0;
+                    else if (row_max[r] - base < 64u) m[c2] &= (1ull << (row_max[r] - base)) - 1ull;
+                }
+                const int c = build_visit_list<kChunks, true>(m, s_list[wave][r], lane, (unsigned short)kNull);   // back to front
+                nsteps = max(nsteps, c);
+                my_cnt = row == r ? c : my_cnt;
             }
-            unsigned short *list = s_list[wave];
-            int nvis = build_visit_list<kBwdBatch / 64, true>(m, list, lane, (unsigned short)kNull);   // back to front
+            const unsigned short *list = s_list[wave][row];
+            float *slab = &s_acc[wave][0][0] + (my_slot >= 0 ? my_slot : 0);
 #if T4D_ABL == 3
-            nvis = 0;
+            nsteps = 0;
 #endif
-            for (int k = 0; k < nvis; k += 4) {
+            for (int k = 0; k < nsteps; k += 4) {
                 const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
-                const int jj[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
+                int jj[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
                 float dxs[4], dys[4], Gs[4], alphas[4];
                 bool contribs[4];
                 bool anyc = false;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
+                    jj[u] = k + u < my_cnt ? jj[u] : kNull;
                     const float2 g_xy = s_xy[jj[u]];
                     dxs[u] = g_xy.x - pxf; dys[u] = g_xy.y - pyf;
                     float p2;
@@ -1133,13 +1177,11 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
                     if (!__any(contrib)) continue;                 // wave-uniform
-                    const int j = __builtin_amdgcn_readfirstlane(jj[u]);
+                    const int j = jj[u];
                     const float dx = dxs[u], dy = dys[u], G = Gs[u], alpha = alphas[u];
-                    float r[10];
-#pragma unroll
-                    for (int q = 0; q < 10; q++) r[q] = 0.f;
+                    float e = 0.f, w = 0.f;
 #if T4D_ABL == 2
-                    if (contrib) r[0] = alpha + G + dx + dy;
+                    if (contrib) e = alpha + G + dx + dy;
                     if (false) {
 #else
                     if (contrib) {
@@ -1150,34 +1192,43 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         const float4 cd = s_cd[j];
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
                         T = T * inv;
-                        const float w = alpha * T;
+                        w = alpha * T;
                         float q = fmaf(cd.x, dp0, fmaf(cd.y, dp1, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
                         acc = fmaf(last_alpha, last_q, (1.f - last_alpha) * acc);
                         last_q = q;
                         last_alpha = alpha;
                         const float dL_dalpha = fmaf(q - acc, T, -tf_bg * inv);
-                        const float e = G * dL_dalpha, ex = e * dx, ey = e * dy;
-                        r[0] = e; r[1] = ex; r[2] = ey;
-                        r[3] = ex * dx; r[4] = ex * dy; r[5] = ey * dy;
-                        r[6] = w * dp0; r[7] = w * dp1; r[8] = w * dp2;
-                        if (DA) r[9] = w * ddep;
+                        e = G * dL_dalpha;
                     }
+                    // lanes that do not contribute carry e = w = 0, so their ten products are exact zeros
+                    const float ex = e * dx, ey = e * dy;
+                    float r[10] = { e, ex, ey, ex * dx, ex * dy, ey * dy, w * dp0, w * dp1, w * dp2, DA ? w * ddep : 0.f };
 #if T4D_ABL == 1 || T4D_ABL == 2
                     if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][j][0] = r[0];
 #else
-                    const float tot = reduce10(r, lane);
-                    if (my_slot >= 0) s_acc[wave][j][my_slot] = tot;
-                    if (kBwdBatch == 64 || j < 64) wrote[0] |= 1ull << (j & 63);
-                    else wrote[kBwdBatch / 64 - 1] |= 1ull << (j - 64);
+                    reduce10_row(r);
+                    const float tot = sel_hi ? r[5] : (sel_mid ? r[3] : r[1]);
+                    // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Two
+                    // rows of the wave may hold the SAME splat in this step (about one step in five): those steps take
+                    // the rows one after the other.  Adding an exact zero changes nothing, so it is skipped.
+                    const uint32_t jc = j == kNull ? (uint32_t)(kNull + 1 + row) : (uint32_t)j;
+                    const uint32_t j0 = lane_value(jc, 0), j1 = lane_value(jc, 16), j2 = lane_value(jc, 32), j3 = lane_value(jc, 48);
+                    const bool add = my_slot >= 0 && tot != 0.f;
+                    float *dst = slab + j * kAcc;
+                    if (j0 != j1 && j0 != j2 && j0 != j3 && j1 != j2 && j1 != j3 && j2 != j3) {
+                        if (add) *dst += tot;
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            if (add && row == rr) *dst += tot;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
 #endif
                 }
             }
-        }
-        __syncthreads();          // every wave has consumed the cull masks
-        if (lane == 0) {
-#pragma unroll
-            for (int c2 = 0; c2 < kBwdBatch / 64; c2++) s_mask[wave][c2] = wrote[c2];
         }
         __syncthreads();
         // ---- write one record per pair (zeros when no wave touched it); fixed wave order => deterministic ----
@@ -1187,13 +1238,12 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             for (int k = 0; k < 10; k++) a[k] = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const unsigned long long m = s_mask[w][tid >> 6];
-                if ((m >> (tid & 63)) & 1ull) {
-                    const float4 *src = reinterpret_cast<const float4 *>(&s_acc[w][tid][0]);
-                    const float4 b0 = src[0], b1 = src[1], b2 = src[2];
-                    a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w;
-                    a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
-                    a[8] += b2.x; a[9] += b2.y;
+                float2 *src = reinterpret_cast<float2 *>(&s_acc[w][tid][0]);
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const float2 b2 = src[k];
+                    a[2 * k] += b2.x; a[2 * k + 1] += b2.y;
+                    src[k] = make_float2(0.f, 0.f);                  // leave the slab zeroed for the next batch
                 }
             }
             const uint32_t pr = s_pair[tid];
