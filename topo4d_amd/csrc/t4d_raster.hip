@@ -794,13 +794,13 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Expand a wave's four 64-bit visit masks into a compact list of staged-splat indices (ascending when !REVERSE,
-// descending when REVERSE), padded with kNull entries so the consumer can always read groups of four.  The
-// hot loops then are plain counted loops: almost no scalar-unit work per splat (the CU's single scalar unit is
-// what bounded the first version of these kernels).
-template <int NCHUNK, bool REVERSE>
-__device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NCHUNK], unsigned short *list, const int lane,
-                                                const unsigned short null_idx)
+// Expand a 64-bit-per-chunk visit mask into a compact list of staged-splat entries (ascending when !REVERSE,
+// descending when REVERSE).  An entry is the splat's slot in the staging arrays times SCALE, i.e. directly the byte
+// offset the consumer needs, so the hot loops spend no instructions on address arithmetic.  The hot loops are plain
+// counted loops: almost no scalar-unit work per splat (the CU's single scalar unit is what bounded the first version
+// of these kernels).
+template <int NCHUNK, bool REVERSE, int SCALE>
+__device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NCHUNK], unsigned short *list, const int lane)
 {
     int cnt = 0;
 #pragma unroll
@@ -809,12 +809,18 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
         const unsigned long long mw = m[c];
         const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
         const int tot = __builtin_popcountll(mw);
-        if ((mw >> lane) & 1ull) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)((c << 6) + lane);
+        if ((mw >> lane) & 1ull) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)(((c << 6) + lane) * SCALE);
         cnt += tot;
     }
-    if (lane < 4) list[cnt + lane] = null_idx;
-    __builtin_amdgcn_wave_barrier();
     return cnt;
+}
+
+// pad a row's list with the null entry up to (and three entries beyond) the wave's longest list: every row then walks
+// the same number of steps without a per-step bounds test
+__device__ __forceinline__ void pad_visit_list(unsigned short *list, const int cnt, const int nsteps, const int lane,
+                                               const unsigned short null_entry)
+{
+    for (int p2 = cnt + lane; p2 < nsteps + 3; p2 += 64) list[p2] = null_entry;
 }
 
 #ifndef T4D_FWD_WAVES
@@ -826,18 +832,13 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     constexpr int kNull = kFwdBatch;                 // staged slot that can never contribute (opacity 0)
     constexpr int kChunks = kFwdBatch / 64;
     constexpr int kListStride = kFwdBatch + 4;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
-    __shared__ float2 s_xy[kFwdBatch + 1];
-    __shared__ float4 s_q[kFwdBatch + 1];            // scaled conic + opacity
-    __shared__ float4 s_cd[kFwdBatch + 1];           // rgb + depth
+    constexpr int kRec = 48;                         // bytes per staged splat: xy (8, +8 pad) | scaled conic + opacity | rgb + depth
+    __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFwdBatch + 1) * kRec];
     __shared__ unsigned long long s_mask[16][kChunks];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
-    if (tid == 0) {
-        s_xy[kNull] = make_float2(0.f, 0.f);
-        s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_cd[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (tid < kRec / 4) reinterpret_cast<float *>(s_rec + kNull * kRec)[tid] = 0.f;
     for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {   // every tile, empty ones last
     const uint4 it = kp.items[item];
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
@@ -867,10 +868,11 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             if (g < (uint32_t)kp.P) {
                 const float2 p = xy[g];
                 const float4 c = co[g];
-                s_xy[tid] = p;
-                s_q[tid] = scale_conic(c);
-                s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
-                                        __uint_as_float((uint32_t)(key >> 32)));
+                unsigned char *rec = s_rec + tid * kRec;
+                *reinterpret_cast<float2 *>(rec) = p;
+                *reinterpret_cast<float4 *>(rec + 16) = scale_conic(c);
+                *reinterpret_cast<float4 *>(rec + 32) = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
+                                                                   __uint_as_float((uint32_t)(key >> 32)));
                 touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
             }
         }
@@ -881,32 +883,34 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         }
         __syncthreads();
         if (__all(done)) continue;                   // wave-uniform; still takes part in the barriers above
-        int nsteps = 0, my_cnt = 0;
+        int nsteps = 0, cnts[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {                // one visit list per 4x4 sub-block (= DPP row) of this wave
             unsigned long long m[kChunks];
 #pragma unroll
             for (int c4 = 0; c4 < kChunks; c4++) m[c4] = uniform_u64(s_mask[wave * 4 + r][c4]);
-            const int cnt = build_visit_list<kChunks, false>(m, s_list[wave][r], lane, (unsigned short)kNull);
-            nsteps = max(nsteps, cnt);
-            my_cnt = row == r ? cnt : my_cnt;
+            cnts[r] = build_visit_list<kChunks, false, kRec>(m, s_list[wave][r], lane);
+            nsteps = max(nsteps, cnts[r]);
         }
+#pragma unroll
+        for (int r = 0; r < 4; r++) pad_visit_list(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kRec));
+        __builtin_amdgcn_wave_barrier();
         const unsigned short *list = s_list[wave][row];
 #if T4D_ABL == 5
         nsteps = 0;
 #endif
+        uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
         for (int k = 0; k < nsteps; k += 4) {
             const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
-            int j[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
+            const uint32_t e[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
             float alpha[4];
             bool valid[4];
             bool anyv = false;
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // four independent evaluations: ILP hides LDS / exp latency
-                j[u] = k + u < my_cnt ? j[u] : kNull;    // rows with shorter lists idle on the null splat
-                const float2 g_xy = s_xy[j[u]];
+                const float2 g_xy = *reinterpret_cast<const float2 *>(s_rec + e[u]);
                 float p2, G;
-                eval_splat(s_q[j[u]], g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha[u]);
+                eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha[u]);
                 valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
                 anyv = anyv || valid[u];
             }
@@ -918,21 +922,21 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // blending is sequential in list order
                 bool ok = valid[u] && !done;
-                if (!__any(ok)) continue;
                 const float test_T = T * (1.f - alpha[u]);
                 const bool stop = ok && test_T < T4D_T_STOP;
                 done = done || stop;
                 ok = ok && !stop;
-                const float4 cd = s_cd[j[u]];
+                const float4 cd = *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);
                 const float w = ok ? alpha[u] * T : 0.f;
                 C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
                 D = fmaf(cd.w, w, D);
                 Wt += w;
                 T = ok ? test_T : T;
-                last_contributor = ok ? b + (uint32_t)j[u] + 1u : last_contributor;
+                last_e = ok ? e[u] : last_e;
             }
             if (__all(done)) break;
         }
+        if (last_e != 0xffffffffu) last_contributor = b + ((last_e * 43691u) >> 21) + 1u;     // entry / 48 for entries < 2^17
     }
     if (inside) {
         const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
@@ -1034,6 +1038,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
     constexpr int kChunks = kBwdBatch / 64;
     constexpr int kListStride = kBwdBatch + 4;
+    constexpr int kEnt = 8;                  // list entries are slot * 8: byte offset into s_xy, half the offset into s_q / s_cd
+    static_assert(kAcc * 4 % kEnt == 0, "slab records must be a whole multiple of the entry scale");
     __shared__ float2 s_xy[kBwdBatch + 1];
     __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
     __shared__ float4 s_cd[kBwdBatch + 1];
@@ -1135,7 +1141,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         }
         __syncthreads();
         if (live) {
-            int nsteps = 0, my_cnt = 0;
+            int nsteps = 0, cnts[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 unsigned long long m[kChunks];
@@ -1147,37 +1153,58 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     if (row_max[r] <= base) m[c2] = 0;
                     else if (row_max[r] - base < 64u) m[c2] &= (1ull << (row_max[r] - base)) - 1ull;
                 }
-                const int c = build_visit_list<kChunks, true>(m, s_list[wave][r], lane, (unsigned short)kNull);   // back to front
-                nsteps = max(nsteps, c);
-                my_cnt = row == r ? c : my_cnt;
+                cnts[r] = build_visit_list<kChunks, true, kEnt>(m, s_list[wave][r], lane);   // back to front
+                nsteps = max(nsteps, cnts[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) pad_visit_list(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kEnt));
+            __builtin_amdgcn_wave_barrier();
+            // Steps in which two rows of this wave hold the SAME splat (about one in five) must not do their slab updates in
+            // one instruction; they are found here, 64 steps per pass, so that the replay only tests a scalar bit.
+            unsigned long long conflict[kChunks];
+#pragma unroll
+            for (int c2 = 0; c2 < kChunks; c2++) {
+                conflict[c2] = 0ull;
+                if ((c2 << 6) < nsteps) {
+                    const int st = (c2 << 6) + lane;
+                    const unsigned short *l0 = s_list[wave][0];
+                    const uint32_t e0 = l0[st], e1 = l0[kListStride + st], e2 = l0[2 * kListStride + st], e3 = l0[3 * kListStride + st];
+                    const uint32_t nul = (uint32_t)(kNull * kEnt);
+                    const bool same = st < nsteps && ((e0 == e1 && e0 != nul) || (e0 == e2 && e0 != nul) || (e0 == e3 && e0 != nul) ||
+                                                      (e1 == e2 && e1 != nul) || (e1 == e3 && e1 != nul) || (e2 == e3 && e2 != nul));
+                    conflict[c2] = __ballot(same);
+                }
             }
             const unsigned short *list = s_list[wave][row];
-            float *slab = &s_acc[wave][0][0] + (my_slot >= 0 ? my_slot : 0);
+            const unsigned char *xy_b = reinterpret_cast<const unsigned char *>(s_xy);
+            const unsigned char *q_b = reinterpret_cast<const unsigned char *>(s_q);
+            const unsigned char *cd_b = reinterpret_cast<const unsigned char *>(s_cd);
+            unsigned char *slab = reinterpret_cast<unsigned char *>(&s_acc[wave][0][0] + (my_slot >= 0 ? my_slot : 0));
+            // entry of the first staged splat this pixel did NOT see in the forward pass (entries are slot * kEnt)
+            const int lc_rel = (int)min(last_contributor - min(last_contributor, lo), (uint32_t)kBwdBatch) * kEnt;
 #if T4D_ABL == 3
             nsteps = 0;
 #endif
             for (int k = 0; k < nsteps; k += 4) {
                 const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
-                int jj[4] = { (int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16) };
+                const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
                 float dxs[4], dys[4], Gs[4], alphas[4];
                 bool contribs[4];
                 bool anyc = false;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
-                    jj[u] = k + u < my_cnt ? jj[u] : kNull;
-                    const float2 g_xy = s_xy[jj[u]];
+                    const float2 g_xy = *reinterpret_cast<const float2 *>(xy_b + ee[u]);
                     dxs[u] = g_xy.x - pxf; dys[u] = g_xy.y - pyf;
                     float p2;
-                    eval_splat(s_q[jj[u]], dxs[u], dys[u], p2, Gs[u], alphas[u]);
-                    contribs[u] = lo + (uint32_t)jj[u] < last_contributor && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
+                    eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), dxs[u], dys[u], p2, Gs[u], alphas[u]);
+                    contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
                     anyc = anyc || contribs[u];
                 }
                 if (!__any(anyc)) continue;
+                const unsigned long long cbits = conflict[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
-                    if (!__any(contrib)) continue;                 // wave-uniform
-                    const int j = jj[u];
                     const float dx = dxs[u], dy = dys[u], G = Gs[u], alpha = alphas[u];
                     float e = 0.f, w = 0.f;
 #if T4D_ABL == 2
@@ -1189,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
                         // the splat centre, and w * dL/dC.  Everything that is constant per splat (opacity, conic,
                         // 0.5*W, -0.5 ...) is applied ONCE per Gaussian after all tiles are summed (k_preprocess_bwd).
-                        const float4 cd = s_cd[j];
+                        const float4 cd = *reinterpret_cast<const float4 *>(cd_b + 2 * ee[u]);
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
                         T = T * inv;
                         w = alpha * T;
@@ -1205,22 +1232,19 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     const float ex = e * dx, ey = e * dy;
                     float r[10] = { e, ex, ey, ex * dx, ex * dy, ey * dy, w * dp0, w * dp1, w * dp2, DA ? w * ddep : 0.f };
 #if T4D_ABL == 1 || T4D_ABL == 2
-                    if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][j][0] = r[0];
+                    if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][0][0] = r[0];
 #else
                     reduce10_row(r);
                     const float tot = sel_hi ? r[5] : (sel_mid ? r[3] : r[1]);
-                    // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Two
-                    // rows of the wave may hold the SAME splat in this step (about one step in five): those steps take
-                    // the rows one after the other.  Adding an exact zero changes nothing, so it is skipped.
-                    const uint32_t jc = j == kNull ? (uint32_t)(kNull + 1 + row) : (uint32_t)j;
-                    const uint32_t j0 = lane_value(jc, 0), j1 = lane_value(jc, 16), j2 = lane_value(jc, 32), j3 = lane_value(jc, 48);
+                    // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).
+                    // Adding an exact zero changes nothing, so it is skipped.
                     const bool add = my_slot >= 0 && tot != 0.f;
-                    float *dst = slab + j * kAcc;
-                    if (j0 != j1 && j0 != j2 && j0 != j3 && j1 != j2 && j1 != j3 && j2 != j3) {
+                    float *dst = reinterpret_cast<float *>(slab + ee[u] * (kAcc * 4 / kEnt));
+                    if (!((cbits >> u) & 1ull)) {
                         if (add) *dst += tot;
                     } else {
 #pragma unroll
-                        for (int rr = 0; rr < 4; rr++) {
+                        for (int rr = 0; rr < 4; rr++) {                 // rows one after the other
                             if (add && row == rr) *dst += tot;
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
