@@ -768,6 +768,9 @@ __device__ __forceinline__ uint32_t subblock_touch_mask(const float2 p, const fl
     return m;
 }
 
+// lane mask of a predicate (the compiler keeps predicates as scalar masks already; this just names one)
+__device__ __forceinline__ unsigned long long ballot64(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // SGPR copy of lane `src_lane`'s value
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
@@ -820,6 +823,7 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
 __device__ __forceinline__ void pad_visit_list(unsigned short *list, const int cnt, const int nsteps, const int lane,
                                                const unsigned short null_entry)
 {
+#pragma clang loop vectorize(disable) unroll(disable)
     for (int p2 = cnt + lane; p2 < nsteps + 3; p2 += 64) list[p2] = null_entry;
 }
 
@@ -905,20 +909,18 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             const uint32_t e[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
             float alpha[4];
             bool valid[4];
-            bool anyv = false;
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // four independent evaluations: ILP hides LDS / exp latency
                 const float2 g_xy = *reinterpret_cast<const float2 *>(s_rec + e[u]);
                 float p2, G;
                 eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha[u]);
                 valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
-                anyv = anyv || valid[u];
             }
 #if T4D_ABL == 4
             if (alpha[0] + alpha[1] + alpha[2] + alpha[3] == 12345.f) C0 += 1.f;
             continue;
 #endif
-            if (!__any(anyv && !done)) continue;
+            // (no "does any lane blend?" test: with four different splats in flight per step the answer is almost always yes)
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // blending is sequential in list order
                 bool ok = valid[u] && !done;
@@ -1190,7 +1192,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                 const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
                 float dxs[4], dys[4], Gs[4], alphas[4];
                 bool contribs[4];
-                bool anyc = false;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
                     const float2 g_xy = *reinterpret_cast<const float2 *>(xy_b + ee[u]);
@@ -1198,9 +1199,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     float p2;
                     eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), dxs[u], dys[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
-                    anyc = anyc || contribs[u];
                 }
-                if (!__any(anyc)) continue;
                 const unsigned long long cbits = conflict[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
