@@ -774,20 +774,26 @@ __device__ __forceinline__ unsigned long long ballot64(const bool p) { return __
 // SGPR copy of lane `src_lane`'s value
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
+typedef float v2f __attribute__((ext_vector_type(2)));      // packed-math pair (v_pk_*_f32 on gfx950)
+
 // The ONE place alpha is evaluated, shared by forward and backward so that both take bit-identical decisions.
-// q = (A, B, C) * log2(e) pre-multiplied by (-0.5, -1, -0.5); returns p2 = power * log2(e), G = exp(power).
-__device__ __forceinline__ void eval_splat(const float4 q, const float dx, const float dy, float &p2, float &G, float &alpha)
+// q = (A, C, B, opacity) with (A, B, C) * log2(e) pre-multiplied by (-0.5, -1, -0.5) - note the ORDER: A and C are
+// adjacent so that (A dx, C dy) is one packed multiply; d = splat centre - pixel.
+// Returns p2 = power * log2(e), G = exp(power).
+__device__ __forceinline__ void eval_splat(const float4 q, const v2f d, float &p2, float &G, float &alpha)
 {
 #pragma clang fp contract(off)
-    p2 = fmaf(q.x * dx, dx, fmaf(q.z * dy, dy, (q.y * dx) * dy));
+    const v2f qac = { q.x, q.y };
+    const v2f m = qac * d;
+    p2 = fmaf(m.x, d.x, fmaf(m.y, d.y, (q.z * d.x) * d.y));
     G = __builtin_amdgcn_exp2f(p2);
     alpha = fminf(T4D_ALPHA_MAX, q.w * G);
 }
 
-__device__ __forceinline__ float4 scale_conic(const float4 co)
+__device__ __forceinline__ float4 scale_conic(const float4 co)      // (A, B, C, opacity) -> scaled (A, C, B, opacity)
 {
 #pragma clang fp contract(off)
-    return make_float4(co.x * (-0.5f * kLog2e), co.y * (-kLog2e), co.z * (-0.5f * kLog2e), co.w);
+    return make_float4(co.x * (-0.5f * kLog2e), co.z * (-0.5f * kLog2e), co.y * (-kLog2e), co.w);
 }
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     int px, py;
     tile_pixel(tid, tx, ty, px, py);
     const bool inside = px < kp.W && py < kp.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const v2f pix_f = { (float)px, (float)py };
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
@@ -911,9 +917,9 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             bool valid[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {                // four independent evaluations: ILP hides LDS / exp latency
-                const float2 g_xy = *reinterpret_cast<const float2 *>(s_rec + e[u]);
+                const v2f g_xy = *reinterpret_cast<const v2f *>(s_rec + e[u]);
                 float p2, G;
-                eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy.x - pxf, g_xy.y - pyf, p2, G, alpha[u]);
+                eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy - pix_f, p2, G, alpha[u]);
                 valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
             }
 #if T4D_ABL == 4
@@ -996,8 +1002,7 @@ __device__ __forceinline__ void reduce10_row(float (&r)[10])
         "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
         : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
 }
 
@@ -1080,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     int px, py;
     tile_pixel(tid, tx, ty, px, py);
     const bool inside = px < kp.W && py < kp.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const v2f pix_f = { (float)px, (float)py };
     const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
 
     float T_final = 0.f, dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f, dalp = 0.f;
@@ -1093,6 +1098,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         if (DA && kp.dL_ddepth) ddep = kp.dL_ddepth[(size_t)v * HW + pix];
         if (DA && kp.dL_dalpha) dalp = kp.dL_dalpha[(size_t)v * HW + pix];
     }
+    const v2f dp01 = { dp0, dp1 };
     float T = T_final;
     // Suffix state of the replay.  Upstream keeps one running "colour behind me" per channel (+ depth, + alpha) and dots
     // it with dL/dpixel afterwards; the recursion is linear, so the dot product is taken FIRST and a single scalar is
@@ -1190,24 +1196,25 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             for (int k = 0; k < nsteps; k += 4) {
                 const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
                 const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
-                float dxs[4], dys[4], Gs[4], alphas[4];
+                v2f ds[4];
+                float Gs[4], alphas[4];
                 bool contribs[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
-                    const float2 g_xy = *reinterpret_cast<const float2 *>(xy_b + ee[u]);
-                    dxs[u] = g_xy.x - pxf; dys[u] = g_xy.y - pyf;
+                    ds[u] = *reinterpret_cast<const v2f *>(xy_b + ee[u]) - pix_f;
                     float p2;
-                    eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), dxs[u], dys[u], p2, Gs[u], alphas[u]);
+                    eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), ds[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
                 }
-                const unsigned long long cbits = conflict[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63);
+                const uint32_t cbits = __builtin_amdgcn_readfirstlane((uint32_t)(conflict[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63)));
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
-                    const float dx = dxs[u], dy = dys[u], G = Gs[u], alpha = alphas[u];
+                    const v2f d = ds[u];
+                    const float G = Gs[u], alpha = alphas[u];
                     float e = 0.f, w = 0.f;
 #if T4D_ABL == 2
-                    if (contrib) e = alpha + G + dx + dy;
+                    if (contrib) e = alpha + G + d.x + d.y;
                     if (false) {
 #else
                     if (contrib) {
@@ -1219,7 +1226,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
                         T = T * inv;
                         w = alpha * T;
-                        float q = fmaf(cd.x, dp0, fmaf(cd.y, dp1, cd.z * dp2));
+                        float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
                         acc = fmaf(last_alpha, last_q, (1.f - last_alpha) * acc);
                         last_q = q;
@@ -1228,8 +1235,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         e = G * dL_dalpha;
                     }
                     // lanes that do not contribute carry e = w = 0, so their ten products are exact zeros
-                    const float ex = e * dx, ey = e * dy;
-                    float r[10] = { e, ex, ey, ex * dx, ex * dy, ey * dy, w * dp0, w * dp1, w * dp2, DA ? w * ddep : 0.f };
+                    const v2f ed = e * d, edd = ed * d, wdp = w * dp01;
+                    float r[10] = { e, ed.x, ed.y, edd.x, ed.x * d.y, edd.y, wdp.x, wdp.y, w * dp2, DA ? w * ddep : 0.f };
 #if T4D_ABL == 1 || T4D_ABL == 2
                     if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][0][0] = r[0];
 #else
@@ -1238,8 +1245,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).
                     // Adding an exact zero changes nothing, so it is skipped.
                     const bool add = my_slot >= 0 && tot != 0.f;
-                    float *dst = reinterpret_cast<float *>(slab + ee[u] * (kAcc * 4 / kEnt));
-                    if (!((cbits >> u) & 1ull)) {
+                    float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], kAcc * 4 / kEnt));
+                    if (!((cbits >> u) & 1u)) {
                         if (add) *dst += tot;
                     } else {
 #pragma unroll
