@@ -834,7 +834,7 @@ __device__ __forceinline__ void pad_visit_list(unsigned short *list, const int c
 }
 
 #ifndef T4D_FWD_WAVES
-#define T4D_FWD_WAVES 7          // 72 VGPRs; measured 3 % faster than the compiler's 80 VGPRs / 6 waves
+#define T4D_FWD_WAVES 6          // 80 VGPRs, no spills; 7 waves (72 VGPRs) spill inside the batch loop and measure 5 % slower
 #endif
 #define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(T4D_FWD_WAVES, T4D_FWD_WAVES)))
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
@@ -1183,6 +1183,9 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     conflict[c2] = __ballot(same);
                 }
             }
+            unsigned long long conflict_s[kChunks];           // the same masks, pinned to scalar registers
+#pragma unroll
+            for (int c2 = 0; c2 < kChunks; c2++) conflict_s[c2] = uniform_u64(conflict[c2]);
             const unsigned short *list = s_list[wave][row];
             const unsigned char *xy_b = reinterpret_cast<const unsigned char *>(s_xy);
             const unsigned char *q_b = reinterpret_cast<const unsigned char *>(s_q);
@@ -1206,7 +1209,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), ds[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
                 }
-                const uint32_t cbits = __builtin_amdgcn_readfirstlane((uint32_t)(conflict[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63)));
+                const uint32_t cbits = (uint32_t)(conflict_s[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63));
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
