@@ -84,6 +84,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--prewarm-s", dest="prewarm_s", type=float, default=0.4,
+                    help="seconds of untimed steps before the W warm-up steps (lets the GPU clocks ramp)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=["C2", "C4"])
     ap.add_argument("--opacity", default="A", choices=["A", "B"])
@@ -207,6 +209,21 @@ def main():
     for i in range(len(rv_frames)):
         step(i)
     topo4d_amd.set_sync_mode("lazy")
+    # A GPU that has just been idle (fresh box, or a profiler run before this one) needs tens of milliseconds of work
+    # before its clocks settle: a cold 50-step run measured 1.23 ms/step against 0.62 warm.  Untimed, like the W steps.
+    torch.cuda.synchronize(dev)
+    t_pre = time.perf_counter()
+    for i in range(8):
+        step(i)
+    torch.cuda.synchronize(dev)
+    est = torch.tensor([(time.perf_counter() - t_pre) / 8], device=dev, dtype=torch.float64)
+    if world > 1:                                   # every rank must run the same number of steps (a step holds a collective)
+        import torch.distributed as dist
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    n_pre = int(min(4000, max(0.0, args.prewarm_s) / max(float(est.item()), 1e-5)))
+    for i in range(n_pre):
+        step(i)
+    torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
 
