@@ -931,9 +931,9 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             for (int u = 0; u < 4; u++) {                // blending is sequential in list order
                 bool ok = valid[u] && !done;
                 const float test_T = T * (1.f - alpha[u]);
-                const bool stop = ok && test_T < T4D_T_STOP;
-                done = done || stop;
-                ok = ok && !stop;
+                const bool below = test_T < T4D_T_STOP;
+                done = done || (ok && below);
+                ok = ok && !below;
                 const float4 cd = *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);
                 const float w = ok ? alpha[u] * T : 0.f;
                 C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
@@ -978,32 +978,45 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 //   levels xor2, xor1 (quad_perm): plain butterflies on r1, r3, r5
 // On return, in lane i = (b3 b2 b1 b0) of a row:  r1 = sum of value 2*b2 + b3,  r3 = sum of value 4 + 2*b2 + b3,
 // r5 = sum of value 8 + b3.
+template <bool NINE>          // NINE: r[9] is known to be zero (no depth cotangent): its banked add is skipped
 __device__ __forceinline__ void reduce10_row(float (&r)[10])
 {
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+#define T4D_RED_HEAD                                                                                  \
+        "s_nop 1\n\t"                                                                                 \
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                           \
+        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                           \
+        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                           \
         "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %3, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %3, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %5, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %5, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define T4D_RED_TAIL                                                                                  \
+        "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
+        "v_add_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
+        "v_add_f32_dpp %3, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
+        "v_add_f32_dpp %3, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
+        "v_add_f32_dpp %5, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
+        "v_add_f32_dpp %5, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                 \
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                 \
         "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-        : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
+    if (NINE) {
+        // %8 then holds the xor8 sum of value 8 in BOTH halves of the row; only the b3 = 0 lane is used (row10_index)
+        asm(T4D_RED_HEAD T4D_RED_TAIL
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]));
+    } else {
+        asm(T4D_RED_HEAD
+            "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            T4D_RED_TAIL
+            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
+    }
+#undef T4D_RED_HEAD
+#undef T4D_RED_TAIL
 }
 
 // which of the ten sums lane i of a row keeps after reduce10_row (taken from r1 / r3 / r5 by (b1 b0)); -1 = none
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
     __shared__ float4 s_cd[kBwdBatch + 1];
     __shared__ uint32_t s_pair[kBwdBatch];
-    __shared__ __attribute__((aligned(8))) float s_acc[4][kBwdBatch][kAcc];
+    __shared__ __attribute__((aligned(8))) float s_acc[4][kBwdBatch + 1][kAcc];   // + the null splat's (never read) row
     __shared__ unsigned long long s_mask[16][kChunks];
     __shared__ uint32_t s_wmax[4];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
@@ -1059,14 +1072,16 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
-    const int my_slot = row10_index(lane & 15);
+    // without a depth cotangent the ninth pair is not transposed (reduce10_row<true>): the lane that would hold sum 9 holds a
+    // second copy of sum 8 and must stay out
+    const int my_slot = (!DA && row10_index(lane & 15) == 9) ? -1 : row10_index(lane & 15);
     const bool sel_mid = (lane & 3) == 1, sel_hi = (lane & 3) == 2;
     if (tid == 0) {
         s_xy[kNull] = make_float2(0.f, 0.f);
         s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_cd[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = tid; i < 4 * kBwdBatch * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
+    for (int i = tid; i < 4 * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
     for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {
     const uint4 it = kp.items[item];
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
@@ -1243,11 +1258,11 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #if T4D_ABL == 1 || T4D_ABL == 2
                     if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][0][0] = r[0];
 #else
-                    reduce10_row(r);
+                    reduce10_row<!DA>(r);
                     const float tot = sel_hi ? r[5] : (sel_mid ? r[3] : r[1]);
-                    // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).
-                    // Adding an exact zero changes nothing, so it is skipped.
-                    const bool add = my_slot >= 0 && tot != 0.f;
+                    // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Idle
+                    // rows add their zeros to the null splat's row, which nobody reads.
+                    const bool add = my_slot >= 0;
                     float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], kAcc * 4 / kEnt));
                     if (!((cbits >> u) & 1u)) {
                         if (add) *dst += tot;
