@@ -51,8 +51,8 @@ constexpr int kFwdBatch = 256;       // splats staged in LDS per round of the fo
 #define T4D_BWD_BATCH 128
 #endif
 constexpr int kBwdBatch = T4D_BWD_BATCH;   // splats staged per round of the backward replay (64 or 128)
-constexpr int kSortLdsCap = 4096;    // keys sorted in LDS (32 KiB); longer bins use the global-memory path
-constexpr int kRankSortMax = 512;    // bins up to this length are sorted by counting ranks (no barriers)
+constexpr int kSortLdsCap = 2048;    // keys sorted in LDS (16 KiB: 8 workgroups per CU); longer bins use the global-memory path
+constexpr int kRankSortMax = 512;    // bins up to this length: register-sorted runs of 64 + one ranking pass (one barrier)
 constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
 constexpr int kBuckets = 24;         // tile-length classes (floor(log2 n), descending; last = empty) for launch ordering
 constexpr int kGP = T4D_GRAD_PAIR_FLOATS;
@@ -415,6 +415,9 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
         kp.radii[vg] = radius;
     }
 
+#if T4D_ABL == 6
+    return;
+#endif
     // ---- pair slots: block-local exclusive scan, ONE returning atomic per workgroup on the view's cursor ----
     const uint32_t incl = wave_incl_scan(tiles);
     const int wave = tid >> 6, lane = tid & 63;
@@ -450,6 +453,9 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     // Gaussians of one workgroup are usually neighbours on the mesh, so they hit few distinct tiles: count them in an
     // LDS histogram over the workgroup's tile bounding box and send ONE returning global atomic per touched tile
     // (instead of one per pair).  Bounding boxes larger than the histogram fall back to per-pair global atomics.
+#if T4D_ABL == 7
+    return;
+#endif
     uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
     uint32_t *prank = kp.pair_rank + (size_t)v * kp.cap;
     const int bbx = s_bb[0], bby = s_bb[1], bw = s_bb[2] - s_bb[0], bh = s_bb[3] - s_bb[1];
@@ -647,10 +653,54 @@ __device__ __forceinline__ void bitonic_any_n(Ptr a, const uint32_t n, const int
     }
 }
 
+// Sort the 64 keys of a wave (one per lane) ascending, entirely in registers: bitonic network whose exchanges are DPP
+// moves (xor 1, 2: quad_perm; xor 4: two bank-masked row shifts; xor 8: row_ror:8) or ds_bpermute (xor 16, 32).
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(const uint32_t v)
+{
+    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    if (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, true);      // banks {0,2} read lane+4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xA, true);  // banks {1,3} read lane-4
+    }
+    if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);
+    return (uint32_t)__shfl_xor((int)v, J, 64);
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step(unsigned long long &key, const int lane)
+{
+    const unsigned long long other = ((unsigned long long)lane_xor<J>((uint32_t)(key >> 32)) << 32) | lane_xor<J>((uint32_t)key);
+    const bool keep_min = ((lane & J) == 0) == ((lane & K) == 0);      // K = 64: every lane sorts ascending
+    key = ((other < key) == keep_min) ? other : key;
+    if constexpr (J > 1) bitonic_step<K, J / 2>(key, lane);
+}
+
+__device__ __forceinline__ void wave_sort64(unsigned long long &key, const int lane)
+{
+    bitonic_step<2, 1>(key, lane);
+    bitonic_step<4, 2>(key, lane);
+    bitonic_step<8, 4>(key, lane);
+    bitonic_step<16, 8>(key, lane);
+    bitonic_step<32, 16>(key, lane);
+    bitonic_step<64, 32>(key, lane);
+}
+
+// number of keys smaller than `key` in a sorted run of 64 (branch-free binary search, 7 LDS reads)
+__device__ __forceinline__ uint32_t run_lower_bound(const unsigned long long *run, const unsigned long long key)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int st = 32; st > 0; st >>= 1)
+        if (run[pos + st - 1] < key) pos += st;
+    return pos + (run[pos] < key ? 1u : 0u);
+}
+
 __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 {
     __shared__ unsigned long long s_keys[kSortLdsCap];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t n_items = (uint32_t)(kp.V * kp.T);
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint4 it = kp.items[item];
@@ -658,51 +708,72 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
         const uint32_t off = it.y, n = it.z;
         if (n < 2) break;                                          // items are ordered by length: nothing left
         unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-        if (n <= (uint32_t)kBlock) {
-            // counting sort by rank, one key per thread: keys are unique (index in the low word), so
-            // rank = #keys smaller than mine.  One barrier, every LDS read is a wave-wide broadcast.
-            const unsigned long long mine = tid < (int)n ? keys[tid] : ~0ull;
-            s_keys[tid] = mine;                                    // padded with +inf up to kBlock
-            __syncthreads();
-            uint32_t rank = 0;
-            if (tid < (int)((n + 63u) & ~63u)) {                   // waves without keys skip the loop
-                const uint32_t n4 = (n + 3u) & ~3u;
-                for (uint32_t i = 0; i < n4; i += 4) {
-                    const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&s_keys[i]);
-                    const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&s_keys[i + 2]);
-                    rank += (ka.x < mine ? 1u : 0u) + (ka.y < mine ? 1u : 0u) + (kb.x < mine ? 1u : 0u) + (kb.y < mine ? 1u : 0u);
+        if (n <= (uint32_t)kRankSortMax) {
+            // Runs of 64 keys are sorted inside a wave's registers (no LDS, no barrier); a key's final position is its
+            // position in its own run plus, for every other run, the number of keys smaller than it (keys are unique: the
+            // Gaussian index is the low word).  One barrier per tile, 7 dependent LDS reads per (key, other run).
+            constexpr int kPer = kRankSortMax / kBlock;             // keys per thread
+            const uint32_t runs = (n + 63u) >> 6;
+            unsigned long long mine[kPer];
+#pragma unroll
+            for (int e = 0; e < kPer; e++) {
+                const uint32_t i = (uint32_t)tid + e * kBlock;     // run (wave + 4 e), position lane
+                if ((uint32_t)(wave + 4 * e) < runs) {             // wave-uniform
+                    mine[e] = i < n ? keys[i] : ~0ull;             // the last run is padded with +inf
+                    wave_sort64(mine[e], lane);
+                    s_keys[i] = mine[e];
                 }
             }
-            if (tid < (int)n) keys[rank] = mine;
-        } else if (n <= (uint32_t)kRankSortMax) {
-            // same with two keys per thread
-            unsigned long long mine[kRankSortMax / kBlock];
-#pragma unroll
-            for (int e = 0; e < kRankSortMax / kBlock; e++) {
-                const uint32_t i = tid + e * kBlock;
-                mine[e] = i < n ? keys[i] : ~0ull;
-                s_keys[i] = mine[e];                              // padded with +inf up to kRankSortMax
-            }
             __syncthreads();
-            uint32_t rank[kRankSortMax / kBlock];
 #pragma unroll
-            for (int e = 0; e < kRankSortMax / kBlock; e++) rank[e] = 0;
-            const uint32_t n4 = (n + 3u) & ~3u;
-            for (uint32_t i = 0; i < n4; i += 4) {
-                const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&s_keys[i]);
-                const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&s_keys[i + 2]);
+            for (int e = 0; e < kPer; e++) {
+                const uint32_t own = (uint32_t)(wave + 4 * e);
+                if (own < runs) {
+                    uint32_t rank = (uint32_t)lane;
 #pragma unroll
-                for (int e = 0; e < kRankSortMax / kBlock; e++)
-                    rank[e] += (ka.x < mine[e] ? 1u : 0u) + (ka.y < mine[e] ? 1u : 0u) + (kb.x < mine[e] ? 1u : 0u) +
-                               (kb.y < mine[e] ? 1u : 0u);
+                    for (uint32_t r = 0; r < (uint32_t)(kRankSortMax / 64); r++)      // unrolled: the searches overlap
+                        if (r < runs && r != own) rank += run_lower_bound(s_keys + ((r & 3u) * 64u + (r >> 2) * kBlock), mine[e]);
+                    if (mine[e] != ~0ull) keys[rank] = mine[e];
+                }
             }
-#pragma unroll
-            for (int e = 0; e < kRankSortMax / kBlock; e++)
-                if (tid + e * kBlock < n) keys[rank[e]] = mine[e];
         } else if (n <= (uint32_t)kSortLdsCap) {
-            for (uint32_t i = tid; i < n; i += kBlock) s_keys[i] = keys[i];
+            // Merge sort by ranking, in place: runs of 64 are sorted in registers, then at every level each key finds
+            // its slot in the merged pair of runs as (position in its own run) + (keys of the sibling run below it),
+            // log2(width)+1 dependent LDS reads; keys wait in registers between the read and the write phase.
+            // log2(n/64) levels with two barriers each (the compare-exchange network needs ~60 barriers at this size).
+            constexpr int kPer = kSortLdsCap / kBlock;
+            const uint32_t runs = (n + 63u) >> 6, N = runs << 6;
+            for (uint32_t r = (uint32_t)wave; r < runs; r += 4) {
+                const uint32_t i = (r << 6) + (uint32_t)lane;
+                unsigned long long k0 = i < n ? keys[i] : ~0ull;
+                wave_sort64(k0, lane);
+                s_keys[i] = k0;
+            }
             __syncthreads();
-            bitonic_any_n(s_keys, n, tid);
+            for (uint32_t w = 64; w < N; w <<= 1) {
+                unsigned long long kk[kPer];
+                uint32_t np[kPer];
+#pragma unroll
+                for (int e = 0; e < kPer; e++) {
+                    const uint32_t p = (uint32_t)tid + e * kBlock;
+                    if (p < N) {
+                        kk[e] = s_keys[p];
+                        const uint32_t run = p / w, sbase = (run ^ 1u) * w;
+                        const uint32_t slen = sbase < N ? min(w, N - sbase) : 0u;
+                        const unsigned long long *sib = s_keys + sbase;
+                        uint32_t pos = 0;
+                        for (uint32_t st = w >> 1; st > 0; st >>= 1)
+                            if (pos + st <= slen && sib[pos + st - 1] < kk[e]) pos += st;
+                        if (pos < slen && sib[pos] < kk[e]) pos++;
+                        np[e] = (run & ~1u) * w + (p & (w - 1u)) + pos;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < kPer; e++)
+                    if ((uint32_t)tid + e * kBlock < N) s_keys[np[e]] = kk[e];
+                __syncthreads();
+            }
             for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
         } else {
             // rare: a bin longer than the LDS buffer is sorted in place in global memory by this workgroup
