@@ -56,6 +56,7 @@ constexpr int kRankSortMax = 512;    // bins up to this length: register-sorted 
 constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
 constexpr int kBuckets = 24;         // tile-length classes (floor(log2 n), descending; last = empty) for launch ordering
 constexpr int kGP = T4D_GRAD_PAIR_FLOATS;
+constexpr int kCursorSegs = 8;       // pair-slot cursors per view (same-address returning atomics are serial: see k_preprocess)
 
 thread_local char g_err[512] = "";
 
@@ -93,7 +94,7 @@ Layout make_layout(const T4DProblem &p)
     size_t o = 0;
     L.status = o;        o = align_up(o + sizeof(DevStatus));
     L.view_total = o;    o = align_up(o + V * 4);
-    L.view_cursor = o;   o = align_up(o + V * 4);
+    L.view_cursor = o;   o = align_up(o + V * kCursorSegs * 4);
     L.tile_count = o;    o = align_up(o + V * T * 4);
     L.bucket_fill = o;   o = align_up(o + kBuckets * 4);
     L.zero_end = o;
@@ -121,6 +122,7 @@ struct KP {
     int V, P, H, W, gx, gy, T, deg, M;
     float scale_modifier;
     uint32_t cap;
+    uint32_t nseg, seg_cap;          // the pair-slot arena of a view is split into nseg segments of seg_cap slots, one cursor each
     const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
     // state
     DevStatus *status;
@@ -435,7 +437,11 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
         if (g < kp.P) kp.pair_off[vg] = 0;
         return;
     }
-    if (tid == 0) s_base = atomicAdd(&kp.view_cursor[v], block_tot);
+    // Returning atomics on ONE address are served one after the other (~0.2 us each): 117 workgroups per view on one
+    // cursor cost this kernel 20 of its 42 us.  The arena is therefore cut into nseg segments with a cursor each;
+    // workgroup b allocates from segment b % nseg (neighbouring workgroups hold mesh neighbours, so the fills stay even).
+    const uint32_t seg = blockIdx.x & (kp.nseg - 1u);
+    if (tid == 0) s_base = seg * kp.seg_cap + atomicAdd(&kp.view_cursor[v * kCursorSegs + seg], block_tot);
     {   // bounding box (in tiles) of everything this workgroup touches
         int bx0 = tiles ? x0 : 0x7fffffff, by0 = tiles ? y0 : 0x7fffffff, bx1 = tiles ? x1 : 0, by1 = tiles ? y1 : 0;
 #pragma unroll
@@ -447,7 +453,10 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     }
     __syncthreads();
     const uint32_t pbase = s_base + wave_off + incl - tiles;
-    if (g < kp.P) kp.pair_off[vg] = pbase;
+    // a Gaussian whose slots do not fit into its segment loses all of them (pair_off = cap fails every later bounds
+    // test); k_scan_tiles raises the overflow flag from the cursors
+    const bool fits = pbase + tiles <= (seg + 1u) * kp.seg_cap;
+    if (g < kp.P) kp.pair_off[vg] = fits ? pbase : kp.cap;
 
     // ---- per-tile counts and the rank of every pair inside its tile ----
     // Gaussians of one workgroup are usually neighbours on the mesh, so they hit few distinct tiles: count them in an
@@ -478,14 +487,14 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
             for (int x = x0; x < x1; x++, pr++) {
                 const int i = (y - bby) * bw + (x - bbx);
                 const uint32_t r = s_hbase[i] + atomicAdd(&s_hist[i], 1u);
-                if (pr < kp.cap) prank[pr] = r;
+                if (fits) prank[pr] = r;
             }
     } else {
         uint32_t pr = pbase;
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++, pr++) {
                 const uint32_t r = atomicAdd(&cnt[y * kp.gx + x], 1u);
-                if (pr < kp.cap) prank[pr] = r;
+                if (fits) prank[pr] = r;
             }
     }
 }
@@ -569,9 +578,12 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
     if (tid == 0) {
         const uint32_t total = s_carry;
         kp.view_total[v] = total;
-        atomicMax(&kp.status->max_pairs, total);
+        uint32_t fill = 0;                                  // fullest pair-slot segment of this view
+        for (uint32_t k = 0; k < kp.nseg; k++) fill = max(fill, kp.view_cursor[v * kCursorSegs + k]);
+        // capacity this view needs: every segment must hold the fullest one
+        atomicMax(&kp.status->max_pairs, max(total, fill * kp.nseg));
         atomicAdd(&kp.status->total_pairs, (unsigned long long)total);
-        if (total > kp.cap) atomicOr(&kp.status->overflow, 1u);
+        if (total > kp.cap || fill > kp.seg_cap) atomicOr(&kp.status->overflow, 1u);
     }
 }
 
@@ -1739,6 +1751,12 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.deg = p.sh_degree; kp.M = p.sh_coeffs;
     kp.scale_modifier = p.scale_modifier;
     kp.cap = (uint32_t)p.pair_capacity;
+    {
+        const uint32_t n_wg = (uint32_t)((p.P + kBlock - 1) / kBlock);
+        kp.nseg = 1;
+        while (kp.nseg < (uint32_t)kCursorSegs && n_wg >= 16u * kp.nseg) kp.nseg <<= 1;       // >= 8 workgroups per cursor
+        kp.seg_cap = kp.cap / kp.nseg;
+    }
     kp.status = reinterpret_cast<DevStatus *>(st + L.status);
     kp.view_total = reinterpret_cast<uint32_t *>(st + L.view_total);
     kp.view_cursor = reinterpret_cast<uint32_t *>(st + L.view_cursor);
