@@ -1294,15 +1294,22 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #if T4D_ABL == 3
             nsteps = 0;
 #endif
+            // The loop is arranged so that no LDS round trip sits between dependent instructions: the list entries of the
+            // NEXT group are fetched while this group is processed, the colour records are fetched together with the
+            // geometry records, and a step's slab value is read BEFORE its arithmetic and written back after it
+            // (same wave, program order: the previous step's write is already ahead of the read in the LDS queue).
+            uint2 pk = *reinterpret_cast<const uint2 *>(list);
             for (int k = 0; k < nsteps; k += 4) {
-                const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
                 const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
+                pk = *reinterpret_cast<const uint2 *>(list + k + 4);          // the lists are padded: always readable
                 v2f ds[4];
                 float Gs[4], alphas[4];
+                float4 cds[4];
                 bool contribs[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
                     ds[u] = *reinterpret_cast<const v2f *>(xy_b + ee[u]) - pix_f;
+                    cds[u] = *reinterpret_cast<const float4 *>(cd_b + 2 * ee[u]);
                     float p2;
                     eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), ds[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
@@ -1313,6 +1320,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     const bool contrib = contribs[u];
                     const v2f d = ds[u];
                     const float G = Gs[u], alpha = alphas[u];
+                    float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], kAcc * 4 / kEnt));
+                    const float old = *dst;              // early read of the slab value this step adds to
                     float e = 0.f, w = 0.f;
 #if T4D_ABL == 2
                     if (contrib) e = alpha + G + d.x + d.y;
@@ -1323,7 +1332,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
                         // the splat centre, and w * dL/dC.  Everything that is constant per splat (opacity, conic,
                         // 0.5*W, -0.5 ...) is applied ONCE per Gaussian after all tiles are summed (k_preprocess_bwd).
-                        const float4 cd = *reinterpret_cast<const float4 *>(cd_b + 2 * ee[u]);
+                        const float4 cd = cds[u];
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
                         T = T * inv;
                         w = alpha * T;
@@ -1339,19 +1348,18 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     const v2f ed = e * d, edd = ed * d, wdp = w * dp01;
                     float r[10] = { e, ed.x, ed.y, edd.x, ed.x * d.y, edd.y, wdp.x, wdp.y, w * dp2, DA ? w * ddep : 0.f };
 #if T4D_ABL == 1 || T4D_ABL == 2
-                    if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] == 12345.f) s_acc[wave][0][0] = r[0];
+                    if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + old == 12345.f) s_acc[wave][0][0] = r[0];
 #else
                     reduce10_row<!DA>(r);
                     const float tot = sel_hi ? r[5] : (sel_mid ? r[3] : r[1]);
                     // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Idle
                     // rows add their zeros to the null splat's row, which nobody reads.
                     const bool add = my_slot >= 0;
-                    float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], kAcc * 4 / kEnt));
                     if (!((cbits >> u) & 1u)) {
-                        if (add) *dst += tot;
+                        if (add) *dst = old + tot;
                     } else {
 #pragma unroll
-                        for (int rr = 0; rr < 4; rr++) {                 // rows one after the other
+                        for (int rr = 0; rr < 4; rr++) {                 // two rows hold the same splat: one after the other
                             if (add && row == rr) *dst += tot;
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             __builtin_amdgcn_wave_barrier();
