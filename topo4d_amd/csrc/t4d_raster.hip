@@ -1077,10 +1077,10 @@ __device__ __forceinline__ void reduce10_row(float (&r)[10])
         "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
 #define T4D_RED_TAIL                                                                                  \
         "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
-        "v_add_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
         "v_add_f32_dpp %3, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
-        "v_add_f32_dpp %3, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
         "v_add_f32_dpp %5, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
+        "v_add_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
+        "v_add_f32_dpp %3, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
         "v_add_f32_dpp %5, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
         "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
         "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
