@@ -185,6 +185,17 @@ int t4d_dense_interpolate(const float *attribute, const int32_t *quad_faces /* [
                           const int32_t *vertex_father /* [n_dense] */, const double *weight /* [n_dense,4] */,
                           int64_t n_coarse, int64_t n_dense, int32_t width, float *out, void *hip_stream);
 
+/* Parameter activations of params2rendervar (helpers.py:91-100: rotations = F.normalize(unnorm_rotations), opacities =
+ * sigmoid(logit_opacities), scales = exp(log_scales)) in one launch, and their vector-Jacobian products in one launch
+ * (torch runs three kernels forward and about a dozen through autograd backward, every iteration: SURVEY.md row a2).
+ * All pointers are device pointers; rotations [P,4], opacities [P,1], scales [P,3].  In the backward a NULL cotangent
+ * counts as zeros and a NULL output is skipped; `opacities` / `scales` are the forward OUTPUTS. */
+int t4d_activate_forward(int64_t P, const float *unnorm_rotations, const float *logit_opacities, const float *log_scales,
+                         float *rotations, float *opacities, float *scales, void *hip_stream);
+int t4d_activate_backward(int64_t P, const float *unnorm_rotations, const float *opacities, const float *scales,
+                          const float *dL_drotations, const float *dL_dopacities, const float *dL_dscales,
+                          float *dL_dunnorm_rotations, float *dL_dlogit_opacities, float *dL_dlog_scales, void *hip_stream);
+
 /* UV-space texture bake (BASELINE config 5): drop-in for the reference's CPU rasterizer
  *     void _render_colors_core(float* image, float* vertices, int* triangles, float* colors, float* depth_buffer,
  *                              int nver, int ntri, int h, int w, int c)        face3d/mesh/cython/mesh_core.h:63-69

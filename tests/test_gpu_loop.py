@@ -82,3 +82,29 @@ def test_per_view_loop_fused_vs_torch_pieces():
         ok = ((pf[k] - pt[k]).abs() <= 0.02 * moved + 3e-5)
         assert ok.float().mean() > 0.97, (k, ok.float().mean(), (pf[k] - pt[k]).abs().max())
     assert torch.equal(mf, mt) and mf.max() > 0
+
+
+def test_fused_activations_match_torch():
+    """t4d_activate_forward/backward vs torch's normalize / sigmoid / exp and their autograd (helpers.py:95-97)."""
+    from topo4d_amd import boundary, scene
+    torch.manual_seed(3)
+    p = scene.make_gaussians(12, 20, opacity="B", seed=5)
+    p["unnorm_rotations"] = p["unnorm_rotations"] * (0.2 + 3 * torch.rand(p["unnorm_rotations"].shape[0], 1))   # not unit length
+    p["unnorm_rotations"][3] = 0.0                                                                      # the eps-clamped branch
+    pa = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p.items()}
+    pb = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p.items()}
+    ra, rb = boundary.params2rendervar(pa), boundary.params2rendervar_fused(pb)
+    for k in ("rotations", "opacities", "scales"):
+        assert rb[k].shape == ra[k].shape
+        torch.testing.assert_close(rb[k], ra[k], rtol=2e-6, atol=1e-7)
+    g = {k: torch.randn_like(ra[k]) for k in ("rotations", "opacities", "scales")}
+    sum((ra[k] * g[k]).sum() for k in g).backward()
+    sum((rb[k] * g[k]).sum() for k in g).backward()
+    for k in ("unnorm_rotations", "logit_opacities", "log_scales"):
+        torch.testing.assert_close(pb[k].grad, pa[k].grad, rtol=2e-5, atol=1e-6)
+    # only some inputs need a gradient
+    pc = {k: v.detach().clone().requires_grad_(k == "log_scales") for k, v in pb.items()}
+    rc = boundary.params2rendervar_fused(pc)
+    (rc["scales"] * g["scales"]).sum().backward()
+    torch.testing.assert_close(pc["log_scales"].grad, pa["log_scales"].grad, rtol=2e-5, atol=1e-6)
+    assert pc["unnorm_rotations"].grad is None

@@ -42,6 +42,10 @@ def it_fused_all(i):
     rv = boundary.params2rendervar(params)
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
     l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); fopt.step(); fopt.zero_grad(set_to_none=True)
+def it_fused_all_act(i):
+    rv = boundary.params2rendervar_fused(params)
+    im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+    l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); fopt.step(); fopt.zero_grad(set_to_none=True)
 def it_torch_all(i):
     rv = boundary.params2rendervar(params)
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
@@ -54,7 +58,8 @@ out = {"workload": "1 view per call, P=8280, 512x375, opacity 1.0 (Topo4D geomet
 for mode in ("checked", "auto", "lazy"):
     topo4d_amd.set_sync_mode("checked")
     for name, fn in (("raster_only", it_raster), ("iter_torch_loss", it_torch_loss), ("iter_fused_loss", it_fused_loss),
-                     ("iter_torch_loss_adam_freezes", it_torch_all), ("iter_fused_loss_adam_pins", it_fused_all)):
+                     ("iter_torch_loss_adam_freezes", it_torch_all), ("iter_fused_loss_adam_pins", it_fused_all),
+                     ("iter_fused_loss_adam_pins_activations", it_fused_all_act)):
         for i in range(30): fn(i)
         topo4d_amd.set_sync_mode(mode)
         torch.cuda.synchronize(); t0 = time.perf_counter()

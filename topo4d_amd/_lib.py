@@ -26,7 +26,7 @@ EXPORTS = (
     "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
     "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end", "t4d_view_dot", "t4d_view_dot_scratch_bytes",
     "t4d_texture_bake", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
-    "t4d_adam_pin_step", "t4d_dense_interpolate",
+    "t4d_adam_pin_step", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
 )
 
 
@@ -126,6 +126,10 @@ def load():
     lib.t4d_dense_interpolate.restype = C.c_int
     lib.t4d_dense_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                           C.c_void_p, C.c_void_p]
+    lib.t4d_activate_forward.restype = C.c_int
+    lib.t4d_activate_forward.argtypes = [C.c_int64] + [C.c_void_p] * 7
+    lib.t4d_activate_backward.restype = C.c_int
+    lib.t4d_activate_backward.argtypes = [C.c_int64] + [C.c_void_p] * 10
     lib.t4d_profile_begin.restype = C.c_int
     lib.t4d_profile_end.restype = C.c_int
     lib.t4d_profile_end.argtypes = [C.POINTER(T4DKernelTime), C.c_int, C.POINTER(C.c_int)]

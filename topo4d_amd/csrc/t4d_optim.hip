@@ -131,3 +131,85 @@ T4D_EXPORT int t4d_dense_interpolate(const float *attribute, const int32_t *quad
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_dense_interpolate launch: %s", hipGetErrorString(e));
     return T4D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Parameter activations of params2rendervar (helpers.py:91-100): rotations = F.normalize(unnorm_rotations),
+// opacities = sigmoid(logit_opacities), scales = exp(log_scales) - three tiny torch kernels forward and, with autograd,
+// about a dozen backward, every iteration.  One launch each way here.
+// F.normalize(x, p=2, dim=1, eps=1e-12) = x / max(||x||_2, eps).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr float kNormEps = 1e-12f;
+
+__global__ __launch_bounds__(256) void k_activate_fwd(long long P, const float4 *unnorm_rot, const float *logit_op, const float *log_scale,
+                                                      float4 *rot, float *op, float *scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4 q = unnorm_rot[i];
+    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), kNormEps);
+    rot[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    op[i] = 1.0f / (1.0f + expf(-logit_op[i]));
+#pragma unroll
+    for (int k = 0; k < 3; k++) scale[3 * i + k] = expf(log_scale[3 * i + k]);
+}
+
+__global__ __launch_bounds__(256) void k_activate_bwd(long long P, const float4 *unnorm_rot, const float *op, const float *scale,
+                                                      const float4 *g_rot, const float *g_op, const float *g_scale,
+                                                      float4 *g_unnorm, float *g_logit, float *g_log_scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    if (g_unnorm) {
+        const float4 q = unnorm_rot[i];
+        const float4 g = g_rot ? g_rot[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (nn > kNormEps) {                             // y = x / n:  dx = (g - y (y . g)) / n
+            const float inv = 1.0f / nn;
+            const float4 y = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+            const float yg = y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
+            g_unnorm[i] = make_float4((g.x - y.x * yg) * inv, (g.y - y.y * yg) * inv, (g.z - y.z * yg) * inv, (g.w - y.w * yg) * inv);
+        } else {                                         // clamped denominator: y = x / eps
+            g_unnorm[i] = make_float4(g.x / kNormEps, g.y / kNormEps, g.z / kNormEps, g.w / kNormEps);
+        }
+    }
+    if (g_logit) {
+        const float s = op[i];
+        g_logit[i] = g_op ? g_op[i] * s * (1.0f - s) : 0.f;
+    }
+    if (g_log_scale) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g_log_scale[3 * i + k] = g_scale ? g_scale[3 * i + k] * scale[3 * i + k] : 0.f;
+    }
+}
+}  // namespace
+
+T4D_EXPORT int t4d_activate_forward(int64_t P, const float *unnorm_rotations, const float *logit_opacities, const float *log_scales,
+                                    float *rotations, float *opacities, float *scales, void *hip_stream)
+{
+    if (P < 0 || (P > 0 && (!unnorm_rotations || !logit_opacities || !log_scales || !rotations || !opacities || !scales)))
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_activate_forward: bad arguments%s", "");
+    if (P == 0) return T4D_OK;
+    hipLaunchKernelGGL(k_activate_fwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (long long)P,
+                       reinterpret_cast<const float4 *>(unnorm_rotations), logit_opacities, log_scales,
+                       reinterpret_cast<float4 *>(rotations), opacities, scales);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_activate_forward launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}
+
+T4D_EXPORT int t4d_activate_backward(int64_t P, const float *unnorm_rotations, const float *opacities, const float *scales,
+                                     const float *dL_drotations, const float *dL_dopacities, const float *dL_dscales,
+                                     float *dL_dunnorm_rotations, float *dL_dlogit_opacities, float *dL_dlog_scales, void *hip_stream)
+{
+    if (P < 0 || (P > 0 && (!unnorm_rotations || !opacities || !scales)))
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_activate_backward: bad arguments%s", "");
+    if (P == 0) return T4D_OK;
+    hipLaunchKernelGGL(k_activate_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (long long)P,
+                       reinterpret_cast<const float4 *>(unnorm_rotations), opacities, scales,
+                       reinterpret_cast<const float4 *>(dL_drotations), dL_dopacities, dL_dscales,
+                       reinterpret_cast<float4 *>(dL_dunnorm_rotations), dL_dlogit_opacities, dL_dlog_scales);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_activate_backward launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}

@@ -19,7 +19,7 @@ from typing import Callable, List, Optional
 import torch
 
 from . import loss as t4d_loss
-from .boundary import params2rendervar
+from .boundary import params2rendervar, params2rendervar_fused
 from .rasterizer import GaussianRasterizer
 
 
@@ -34,9 +34,11 @@ def get_batch(todo_dataset: list, dataset: list, rng: Random, idx: Optional[int]
     return curr, todo_dataset
 
 
-def photometric_iteration(params, curr_data, fused_loss: bool = True, extra_loss: Optional[Callable] = None):
+def photometric_iteration(params, curr_data, fused_loss: bool = True, extra_loss: Optional[Callable] = None,
+                          fused_activations: bool = True):
     """One forward of get_loss's photometric branch (train.py:303-328, use_mask False); returns (loss, radius)."""
-    rendervar = params2rendervar(params)
+    on_gpu = params['means3D'].is_cuda
+    rendervar = params2rendervar_fused(params) if (fused_activations and on_gpu) else params2rendervar(params)
     rendervar['means2D'].retain_grad()
     im, radius, _, _ = GaussianRasterizer(raster_settings=curr_data['cam'])(**rendervar)
     cid = curr_data['id']
