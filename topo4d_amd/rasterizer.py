@@ -159,7 +159,10 @@ def pack_views(settings: Sequence[GaussianRasterizationSettings], device) -> tor
             _VIEW_CACHE.clear()
         _VIEW_CACHE[key] = (s, ver, rec)
         recs.append(rec)
-    out = torch.stack(recs, 0).contiguous()
+    if len(recs) == 1:
+        out = recs[0].unsqueeze(0)                           # a view of the cached record: no kernel, no allocation
+    else:
+        out = torch.stack(recs, 0)
     assert out.shape[1] == T4D_VIEW_FLOATS
     return out
 
@@ -189,6 +192,14 @@ def _f32c(t: Optional[torch.Tensor], name: str, device) -> Optional[torch.Tensor
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def _raw_stream(device) -> int:
+    """hipStream_t of torch's current stream on `device` (the private getter is ~20x cheaper than building a Stream object)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:                                   # pragma: no cover - older/newer torch without the private hook
+        return torch.cuda.current_stream(device).cuda_stream
 
 
 class ViewBatch:
@@ -230,7 +241,7 @@ class ViewBatch:
                           cap, flags, 0)
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(_raw_stream(self.device))
 
     # -- forward ---------------------------------------------------------------------------------------------
     def forward(self, means3D, opacities, scales=None, rotations=None, colors_precomp=None, shs=None,
@@ -341,6 +352,8 @@ class ViewBatch:
             raise ValueError("dL_dcolor must be [V,3,H,W]")
         dL_ddepth = _f32c(dL_ddepth, "dL_ddepth", dev)
         dL_dalpha = _f32c(dL_dalpha, "dL_dalpha", dev)
+        # separate allocations on purpose: autograd's AccumulateGrad only adopts a gradient without copying it when the
+        # tensor owns its storage (carving them out of one buffer cost six clone kernels per backward)
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         g = dict(means3D=new(V, P, 3), means2D=new(V, P, 3), opacities=new(V, P, 1))
         g["colors_precomp"] = new(V, P, 3) if colors_precomp is not None else None
