@@ -44,7 +44,7 @@ extern "C" {
 
 #define T4D_ABI_VERSION 1
 #define T4D_VIEW_FLOATS 40
-#define T4D_GRAD_PAIR_FLOATS 12   /* per (Gaussian,tile) partial-gradient record in the backward scratch */
+#define T4D_GRAD_PAIR_FLOATS 10   /* per (Gaussian,tile) partial-gradient record in the backward scratch */
 
 enum {
     T4D_OK = 0,

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libtopo4d_raster.so")
 
 T4D_ABI_VERSION = 1
 T4D_VIEW_FLOATS = 40
-T4D_GRAD_PAIR_FLOATS = 12
+T4D_GRAD_PAIR_FLOATS = 10
 
 T4D_OK, T4D_ERR_ARG, T4D_ERR_HIP, T4D_ERR_PAIR_OVERFLOW, T4D_ERR_STATE_SIZE = 0, 1, 2, 3, 4
 T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_PREFILTERED, T4D_FLAG_ASYNC_STATUS = 1, 2, 4, 8

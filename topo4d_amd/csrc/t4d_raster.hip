@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     constexpr int kChunks = kBwdBatch / 64;
     constexpr int kListStride = kBwdBatch + 4;
     constexpr int kEnt = 8;                  // list entries are slot * 8: byte offset into s_xy, half the offset into s_q / s_cd
+    static_assert(kGP == kAcc, "the slab entry and the scratch record hold the same ten sums");
     static_assert(kAcc * 4 % kEnt == 0, "slab records must be a whole multiple of the entry scale");
     __shared__ float2 s_xy[kBwdBatch + 1];
     __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
     const int32_t *radii = kp.radii + (size_t)v * kp.P;
     const uint32_t *pair_off = kp.pair_off + (size_t)v * kp.P;
-    float4 *grad_pair = reinterpret_cast<float4 *>(kp.grad_pair) + (size_t)v * kp.cap * 3;
+    float2 *grad_pair = reinterpret_cast<float2 *>(kp.grad_pair) + (size_t)v * kp.cap * (kGP / 2);
     const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
 
     int px, py;
@@ -1387,9 +1388,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             }
             const uint32_t pr = s_pair[tid];
             if (pr < kp.cap) {
-                grad_pair[(size_t)pr * 3] = make_float4(a[0], a[1], a[2], a[3]);
-                grad_pair[(size_t)pr * 3 + 1] = make_float4(a[4], a[5], a[6], a[7]);
-                grad_pair[(size_t)pr * 3 + 2] = make_float4(a[8], a[9], 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < kGP / 2; k++) grad_pair[(size_t)pr * (kGP / 2) + k] = make_float2(a[2 * k], a[2 * k + 1]);
             }
         }
         __syncthreads();
@@ -1422,15 +1422,16 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
         tile_rect(p2.x, p2.y, radius, kp.gx, kp.gy, x0, y0, x1, y1);
         const uint32_t npairs = (uint32_t)((x1 - x0) * (y1 - y0));
         const uint32_t base = kp.pair_off[vg];
-        const float4 *gp = reinterpret_cast<const float4 *>(kp.grad_pair) + (size_t)v * kp.cap * 3;
+        const float2 *gp = reinterpret_cast<const float2 *>(kp.grad_pair) + (size_t)v * kp.cap * (kGP / 2);
         float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, gdep = 0.f;
         for (uint32_t k = 0; k < npairs; k++) {
             const uint32_t pr = base + k;
             if (pr >= kp.cap) break;
-            const float4 a0 = gp[(size_t)pr * 3], a1 = gp[(size_t)pr * 3 + 1], a2 = gp[(size_t)pr * 3 + 2];
-            S0 += a0.x; S1 += a0.y; S2 += a0.z; S3 += a0.w;
-            S4 += a1.x; S5 += a1.y; grgb[0] += a1.z; grgb[1] += a1.w;
-            grgb[2] += a2.x; gdep += a2.y;
+            const float2 *rec = gp + (size_t)pr * (kGP / 2);           // 40-byte records: 8-byte aligned
+            const float2 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
+            S0 += a0.x; S1 += a0.y; S2 += a1.x; S3 += a1.y;
+            S4 += a2.x; S5 += a2.y; grgb[0] += a3.x; grgb[1] += a3.y;
+            grgb[2] += a4.x; gdep += a4.y;
         }
         // per-splat constants applied once (see k_render_bwd): dL/dG = opacity * dL/dalpha, dG/dd = -G * conic * d
         const float4 cq = kp.conic_opacity[vg];
