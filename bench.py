@@ -95,6 +95,11 @@ def main():
                     help="split the views of a step over this many HIP streams (independent views overlap their kernel tails)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 1000),
+                                   os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
