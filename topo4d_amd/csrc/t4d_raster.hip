@@ -46,7 +46,10 @@ namespace {
 #define T4D_ABL 0
 #endif
 constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave64)
-constexpr int kFwdBatch = 256;       // splats staged in LDS per round of the forward blend
+#ifndef T4D_FWD_BATCH
+#define T4D_FWD_BATCH 256
+#endif
+constexpr int kFwdBatch = T4D_FWD_BATCH;   // splats staged in LDS per round of the forward blend (one per thread: <= 256)
 #ifndef T4D_BWD_BATCH
 #define T4D_BWD_BATCH 128
 #endif
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     for (uint32_t b = 0; b < n; b += kFwdBatch) {
         if (__syncthreads_count(done) == kBlock) break;
         uint32_t touch = 0;
-        if (b + tid < n) {
+        if (tid < kFwdBatch && b + tid < n) {
             const unsigned long long key = keys[b + tid];
             const uint32_t g = (uint32_t)key;
             // g >= P only happens in lazy mode after an arena overflow (slots of dropped pairs hold stale bytes):
@@ -969,10 +972,12 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
             }
         }
+        if (wave < kChunks) {
 #pragma unroll
-        for (int sb = 0; sb < 16; sb++) {
-            const unsigned long long bal = __ballot((touch >> sb) & 1u);
-            if (lane == sb) s_mask[sb][wave] = bal;
+            for (int sb = 0; sb < 16; sb++) {
+                const unsigned long long bal = __ballot((touch >> sb) & 1u);
+                if (lane == sb) s_mask[sb][wave] = bal;
+            }
         }
         __syncthreads();
         if (__all(done)) continue;                   // wave-uniform; still takes part in the barriers above
