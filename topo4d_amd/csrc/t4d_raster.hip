@@ -10,18 +10,22 @@
 //     (depth bits << 32 | Gaussian index).  That reproduces upstream's order (stable radix sort on tile|depth of
 //     pairs emitted in index order) without a global sort and without a host round trip;
 //   * tiles are processed in descending list length (work items built on the device), which balances the 8 XCDs;
-//   * the backward never uses global atomics: each tile writes one raw-moment record per (Gaussian,tile) pair after a
-//     wave64 transpose-reduce + fixed-order cross-wave sum, and the per-Gaussian kernel gathers its pairs in fixed
-//     order.  Gradients are bit-reproducible run to run.
+//   * inside a tile every 16-lane DPP row owns a 4x4 pixel sub-block with its own culled visit list, so the four rows of
+//     a wave work on four different splats at a time;
+//   * the backward uses no atomics at all: ten sums per (row,splat) are reduced with bank-masked DPP adds, added to
+//     per-wave LDS slabs by plain read-add-write, summed over the waves in fixed order into one raw-moment record per
+//     (Gaussian,tile) pair, and the per-Gaussian kernel gathers its pairs in fixed order.  Gradients are
+//     bit-reproducible run to run.
 //
 // Kernels (DESIGN.md has the bytes/roofline of each):
 //   k_preprocess      A.1  per (view,Gaussian): cull, project, cov3D, EWA cov2D, conic, radius, tile rect, SH colour;
 //                          + per-tile counts and pair ranks + pair-slot allocation (one returning atomic per workgroup)
 //   k_scan_tiles      A.2  per view: exclusive scan of tile counts -> tile offsets, overflow status, length buckets
 //   k_scatter         A.2  per (view,Gaussian): key -> tile_off + rank (no atomics); tail blocks build the work items
-//   k_sort_tiles      A.2  per work item: sort the bin by (depth bits, index): rank sort / LDS bitonic / global bitonic
-//   k_render_fwd      A.3  per work item: 256 threads = 4 wave64, each wave an 8x8 pixel block; front-to-back blend
-//   k_render_bwd      A.4  per work item: back-to-front replay, wave64 transpose-reduce, one record per pair
+//   k_sort_tiles      A.2  per work item: sort the bin by (depth bits, index): runs of 64 sorted in registers, merged by
+//                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS); global bitonic beyond
+//   k_render_fwd      A.3  per work item: 256 threads = 4 wave64 = 16 DPP rows, one 4x4 sub-block each; front-to-back blend
+//   k_render_bwd      A.4  per work item: back-to-front replay, row-local reduction, one record per pair
 //   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D/SH chain rule
 //   k_view_dot_*, k_mark_visible: small utilities of the ABI
 #include <hip/hip_runtime.h>
@@ -41,7 +45,7 @@ namespace {
 // T4D_ABL (ablation builds, tools/ablate.sh; never defined in the shipped library):
 //   1 = backward: skip the cross-lane reduction + LDS slab write      2 = backward: skip the gradient arithmetic too
 //   3 = backward: skip the whole visit loop (staging + write-out only) 4 = forward: skip blending (alpha evaluation only)
-//   5 = forward: skip the whole visit loop
+//   5 = forward: skip the whole visit loop      6 / 7 = preprocess: stop before / after the pair-slot allocation
 #ifndef T4D_ABL
 #define T4D_ABL 0
 #endif
@@ -192,14 +196,6 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
-}
-
-// un-normalised quaternion (r,x,y,z) -> rotation, row-major (same matrix as reference external.py:26-43)
 __device__ __forceinline__ void quat_rot(const float4 q, float R[9])
 {
 #pragma clang fp contract(off)
@@ -854,9 +850,6 @@ __device__ __forceinline__ uint32_t subblock_touch_mask(const float2 p, const fl
     return m;
 }
 
-// lane mask of a predicate (the compiler keeps predicates as scalar masks already; this just names one)
-__device__ __forceinline__ unsigned long long ballot64(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
-
 // SGPR copy of lane `src_lane`'s value
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
@@ -1055,7 +1048,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 // vectors are folded into one, each half of the lanes keeping a different value, so the work halves per level
 // instead of staying at 10 adds x 4 levels.  Levels: xor8 by row_ror:8, xor4 by two bank-masked row shifts, xor2 /
 // xor1 by quad_perm.  The four rows of a wave reduce four different splats at the same time.
-// On return lane i of a row holds the row-wide sum of value row10_index(i) (or garbage when that is < 0).
 // ---------------------------------------------------------------------------------------------------------
 // In-place butterfly over ten VGPRs, written as one asm block: bank-masked DPP adds do the "keep one half, send the
 // other" selection of the transpose for free (v_cndmask + v_mov_dpp pairs otherwise), and the instruction order keeps
@@ -1131,8 +1123,9 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 // record (raw sums over the tile's pixels, e = G * dL/dalpha, d = splat centre - pixel):
 //   [0] sum e   [1,2] sum e*d   [3,4,5] sum e*dx*dx, e*dx*dy, e*dy*dy   [6,7,8] sum alpha*T*dL/dC   [9] sum alpha*T*dL/dD
 // Inside the workgroup every wave owns an LDS slab of ten sums per staged splat; a row's reduced sums are added to it
-// with ds_add_f32 (at most four lanes - the wave's four rows - ever hit one address, in one instruction, so the order
-// of the additions is fixed), and the slabs of the four waves are summed in wave order when the batch is written out.
+// by plain read-add-write (no LDS float atomics: they retire ~3 cycles per lane here), rows that hold the same splat
+// in the same step taking turns, and the slabs of the four waves are summed in wave order when the batch is written
+// out.  Every addition order is fixed, so the gradients are bit-reproducible.
 // ---------------------------------------------------------------------------------------------------------
 // DA = the caller supplied dL/ddepth and/or dL/dalpha.  Topo4D discards depth and alpha (train.py:307), so its backward
 // runs the DA = false instantiation, which carries neither the two extra suffix accumulators nor their products.
