@@ -176,6 +176,12 @@ typedef struct T4DAdamTensor {
 } T4DAdamTensor;
 int t4d_adam_pin_step(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
                       void *hip_stream);
+/* The same step with its per-tensor hyper-parameters in DEVICE memory, so that the launch can be recorded in a HIP graph
+ * and replayed: step_dev [n_tensors] int32 step counts (advanced by this call for the tensors that have a gradient, then
+ * used for the bias corrections), lr_dev [n_tensors] float learning rates.  The `step` and `lr` fields of the descriptors
+ * are ignored.  Bias corrections are evaluated in double precision on the device: results equal t4d_adam_pin_step's. */
+int t4d_adam_pin_step_graph(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
+                            int32_t *step_dev, const float *lr_dev, void *hip_stream);
 
 /* Dense-attribute interpolation: helpers.py:237-253 `compute_vertex_attribute_by_weight_2` on the device (Topo4D runs it in
  * numpy after a device->host copy every frame, train.py:504-506).  out [n_coarse+n_dense, width]: the first n_coarse rows

@@ -108,3 +108,59 @@ def test_fused_activations_match_torch():
     (rc["scales"] * g["scales"]).sum().backward()
     torch.testing.assert_close(pc["log_scales"].grad, pa["log_scales"].grad, rtol=2e-5, atol=1e-6)
     assert pc["unnorm_rotations"].grad is None
+
+
+def test_graphed_views_replay_equals_the_eager_loop():
+    """loop.GraphedViews (one HIP graph per camera: activations -> render -> loss -> backward -> Adam + pins) against the
+    same iterations issued eagerly, same camera schedule, changing a learning rate on the way."""
+    import topo4d_amd
+    from tests import util
+    from topo4d_amd import loop, scene
+    from topo4d_amd.optim import FusedAdamPins
+    H = W = 64
+    p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)
+    p0['log_scales'] = p0['log_scales'] + torch.randn(240, 3, generator=torch.Generator().manual_seed(9)) * 0.3
+    p0['cam_m'] = torch.zeros(3, 3); p0['cam_c'] = torch.zeros(3, 3)
+    cams = util.to_device(scene.camera_rig(H, W, n_views=3), "cuda")
+    g = torch.Generator().manual_seed(5)
+    dataset = [{'cam': cams[i], 'im': torch.rand(3, H, W, generator=g).cuda(), 'id': i} for i in range(3)]
+    lrs = {'means3D': 1.6e-4, 'rgb_colors': 0.0025, 'unnorm_rotations': 0.001, 'logit_opacities': 0.0, 'log_scales': 0.001,
+           'cam_m': 1e-4, 'cam_c': 1e-4}
+    schedule = [0, 2, 1, 1, 0, 2, 2, 0, 1, 0]
+    pins = torch.arange(0, 240, 5).cuda()
+
+    def run(graphed):
+        params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=graphed)
+        opt.set_pin('means3D', pins, params['means3D'][pins].detach().clone())
+        losses = []
+        if graphed:
+            gv = loop.GraphedViews(params, dataset, opt)
+        topo4d_amd.set_sync_mode("lazy")
+        try:
+            for it, c in enumerate(schedule):
+                if it == 5:
+                    for grp in opt.param_groups:                    # helpers.update_optimizer between stages
+                        if grp['name'] == 'rgb_colors':
+                            grp['lr'] = 0.00025
+                if graphed:
+                    losses.append(gv.step(c).clone())
+                else:
+                    l, _, _ = loop.photometric_iteration(params, dataset[c])
+                    l.backward()
+                    opt.step(); opt.zero_grad(set_to_none=True)
+                    losses.append(l.detach().clone())
+            if graphed:
+                gv.check()
+                assert opt.steps()[0] == len(schedule)
+        finally:
+            topo4d_amd.set_sync_mode("checked")
+        return {k: v.detach().clone() for k, v in params.items()}, torch.stack(losses)
+
+    # capacity for the eager run is learned by the graphed run's warm-up (same scene, same cameras)
+    pg, lg = run(True)
+    pe, le = run(False)
+    assert torch.allclose(lg, le, rtol=1e-6, atol=1e-7), (lg, le)
+    for k in pg:
+        assert torch.allclose(pg[k], pe[k], rtol=2e-6, atol=1e-7), (k, (pg[k] - pe[k]).abs().max())
+    assert torch.equal(pg['means3D'][pins], p0['means3D'].cuda()[pins])

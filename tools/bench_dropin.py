@@ -55,6 +55,20 @@ def it_torch_all(i):
             params["means3D"][static_idx] = static_vals
 
 out = {"workload": "1 view per call, P=8280, 512x375, opacity 1.0 (Topo4D geometry pass shape)"}
+
+# the same full iteration recorded in one HIP graph per camera and replayed (loop.GraphedViews)
+from topo4d_amd import loop as t4d_loop
+gparams = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+gopt = FusedAdamPins([{"params": [v], "name": k, "lr": 1e-4} for k, v in gparams.items()], eps=1e-15, capturable=True)
+gopt.set_pin("means3D", torch.arange(0, 8280, 5), gparams["means3D"][::5].detach().clone())
+gdata = [{"cam": cams[i], "im": gts[i], "id": i} for i in range(24)]
+gv = t4d_loop.GraphedViews(gparams, gdata, gopt)
+for i in range(48): gv.step(i % 24)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(2000): gv.step(i % 24)
+torch.cuda.synchronize()
+out["iter_fused_everything_hip_graph_it_per_s"] = round(2000 / (time.perf_counter() - t0), 1)
+gv.check()
 for mode in ("checked", "auto", "lazy"):
     topo4d_amd.set_sync_mode("checked")
     for name, fn in (("raster_only", it_raster), ("iter_torch_loss", it_torch_loss), ("iter_fused_loss", it_fused_loss),

@@ -26,7 +26,7 @@ EXPORTS = (
     "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
     "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end", "t4d_view_dot", "t4d_view_dot_scratch_bytes",
     "t4d_texture_bake", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
-    "t4d_adam_pin_step", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
+    "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
 )
 
 
@@ -123,6 +123,9 @@ def load():
     lib.t4d_photometric_loss.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p]
     lib.t4d_adam_pin_step.restype = C.c_int
     lib.t4d_adam_pin_step.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    lib.t4d_adam_pin_step_graph.restype = C.c_int
+    lib.t4d_adam_pin_step_graph.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
     lib.t4d_dense_interpolate.restype = C.c_int
     lib.t4d_dense_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                           C.c_void_p, C.c_void_p]

@@ -25,18 +25,41 @@ constexpr int kBlock = 256;
 struct AdamArgs {
     T4DAdamTensor t[kMaxTensors];
     long long first_block[kMaxTensors + 1];    // exclusive prefix of the per-tensor block counts
-    float step_size[kMaxTensors];              // lr / (1 - beta1^t)
+    float step_size[kMaxTensors];              // lr / (1 - beta1^t)                (host-side hyper-parameters)
     float inv_bc2_sqrt[kMaxTensors];           // 1 / sqrt(1 - beta2^t)
+    const int32_t *step_dev;                   // device-side hyper-parameters (graph replays): step counts, already advanced
+    const float *lr_dev;
     int n;
     float beta1, beta2, eps;
 };
 
+// advances the device-side step counters of the tensors that take a gradient step (one thread per tensor)
+__global__ void k_adam_tick(int32_t *step_dev, const uint32_t has_grad_mask, const int n)
+{
+    const int k = threadIdx.x;
+    if (k < n && ((has_grad_mask >> k) & 1u)) step_dev[k] += 1;
+}
+
+template <bool DEV>
 __global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
 {
     int k = 0;
 #pragma unroll
     for (int i = 1; i < kMaxTensors; i++) k += (i < A.n && (long long)blockIdx.x >= A.first_block[i]) ? 1 : 0;
     const T4DAdamTensor &T = A.t[k];
+    float step_size = A.step_size[k], inv_bc2_sqrt = A.inv_bc2_sqrt[k];
+    if (DEV) {
+        // same double-precision bias corrections as the host path, from the counters kept in device memory
+        __shared__ float s_hyper[2];
+        if (threadIdx.x == 0) {
+            const double st = T.grad ? (double)A.step_dev[k] : 1.0;
+            const double bc1 = 1.0 - pow((double)A.beta1, st), bc2 = 1.0 - pow((double)A.beta2, st);
+            s_hyper[0] = (float)((double)A.lr_dev[k] / bc1);
+            s_hyper[1] = (float)(1.0 / sqrt(bc2));
+        }
+        __syncthreads();
+        step_size = s_hyper[0]; inv_bc2_sqrt = s_hyper[1];
+    }
     const long long i = ((long long)blockIdx.x - A.first_block[k]) * kBlock + threadIdx.x;
     const long long numel = T.rows * T.width;
     if (i >= numel) return;
@@ -48,30 +71,33 @@ __global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
         v = fmaf(1.f - A.beta2, g * g, A.beta2 * v);
         T.exp_avg[i] = m;
         T.exp_avg_sq[i] = v;
-        const float denom = sqrtf(v) * A.inv_bc2_sqrt[k] + A.eps;
-        p = p - A.step_size[k] * (m / denom);
+        const float denom = sqrtf(v) * inv_bc2_sqrt + A.eps;
+        p = p - step_size * (m / denom);
     }
     if (T.pin_mask && T.pin_mask[i / T.width]) p = T.pin_values[i];
     T.param[i] = p;
 }
 
-}  // namespace
-
-T4D_EXPORT int t4d_adam_pin_step(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps,
-                                 void *hip_stream)
+int adam_launch(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps, int32_t *step_dev,
+                const float *lr_dev, void *hip_stream)
 {
     if (!tensors || n_tensors < 1 || n_tensors > kMaxTensors)
         return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: 1..T4D_ADAM_MAX_TENSORS tensors%s", "");
+    if ((step_dev == nullptr) != (lr_dev == nullptr))
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step_graph: step_dev and lr_dev go together%s", "");
     AdamArgs A;
     memset(&A, 0, sizeof(A));
     A.n = n_tensors; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
+    A.step_dev = step_dev; A.lr_dev = lr_dev;
     long long blocks = 0;
+    uint32_t has_grad = 0;
     for (int k = 0; k < n_tensors; k++) {
         const T4DAdamTensor &t = tensors[k];
         if (!t.param || t.rows < 0 || t.width < 1 || (t.grad && (!t.exp_avg || !t.exp_avg_sq)) || ((t.pin_mask == nullptr) != (t.pin_values == nullptr)))
             return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: inconsistent tensor descriptor%s", "");
-        if (t.grad && t.step < 1) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: step must be >= 1%s", "");
+        if (!step_dev && t.grad && t.step < 1) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: step must be >= 1%s", "");
         A.t[k] = t;
+        if (t.grad) has_grad |= 1u << k;
         const double st = t.grad ? (double)t.step : 1.0;
         const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
         A.step_size[k] = (float)((double)t.lr / bc1);
@@ -82,10 +108,30 @@ T4D_EXPORT int t4d_adam_pin_step(const T4DAdamTensor *tensors, int32_t n_tensors
     A.first_block[n_tensors] = blocks;
     if (blocks == 0) return T4D_OK;
     if (blocks > 0x7fffffffLL) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: too many elements%s", "");
-    hipLaunchKernelGGL(k_adam_pin, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, A);
+    if (step_dev) {
+        hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, step_dev, has_grad, (int)n_tensors);
+        hipLaunchKernelGGL(k_adam_pin<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, A);
+    } else {
+        hipLaunchKernelGGL(k_adam_pin<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, A);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_adam_pin_step launch: %s", hipGetErrorString(e));
     return T4D_OK;
+}
+
+}  // namespace
+
+T4D_EXPORT int t4d_adam_pin_step(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps,
+                                 void *hip_stream)
+{
+    return adam_launch(tensors, n_tensors, beta1, beta2, eps, nullptr, nullptr, hip_stream);
+}
+
+T4D_EXPORT int t4d_adam_pin_step_graph(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps,
+                                       int32_t *step_dev, const float *lr_dev, void *hip_stream)
+{
+    if (!step_dev || !lr_dev) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step_graph: step_dev and lr_dev are required%s", "");
+    return adam_launch(tensors, n_tensors, beta1, beta2, eps, step_dev, lr_dev, hip_stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ scope; `extra_loss` lets a caller add them as plain torch.
 """
 from __future__ import annotations
 
+import warnings
 from random import Random
 from typing import Callable, List, Optional
 
@@ -73,3 +74,104 @@ def optimise_views(params, dataset: List[dict], optimizer, n_iters: int, seed: i
                 max_2D_radius[seen] = torch.max(radius[seen], max_2D_radius[seen])
         losses.append(l.detach())
     return losses
+
+
+class GraphedViews:
+    """The same iteration (activations -> render -> photometric loss -> backward -> Adam + pins), recorded ONCE per camera
+    in a HIP graph and replayed: the reference's loop is launch-bound (about 25 launches of microseconds each per
+    iteration, train.py:661-700), so replaying a graph removes the host from the loop.
+
+        opt = FusedAdamPins(groups, eps=1e-15, capturable=True)
+        gv = GraphedViews(params, dataset, opt)            # warm-up (learns the pair-arena size), then one capture per camera
+        for it in range(n):
+            curr_index = rng.randint(0, len(dataset) - 1)  # any schedule: the graphs are indexed by camera
+            loss = gv.step(curr_index)                     # device scalar of that iteration (no synchronisation)
+        gv.check()                                         # once in a while: raises if a replay outgrew its pair arena
+
+    Parameters, optimiser state and pins are the caller's tensors (updated in place by the replays); `opt.param_groups[i]
+    ['lr']` may be changed between steps (helpers.update_optimizer does) - step() pushes it to the device copy.
+    Replays are un-synchronised like the rasterizer's "lazy" mode: the arena learned during warm-up has 1.5x head-room;
+    gv.check() reads the overflow flags back.
+    """
+
+    def __init__(self, params, dataset: List[dict], optimizer, fused_loss: bool = True, extra_loss: Optional[Callable] = None):
+        from . import rasterizer as R
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedViews needs FusedAdamPins(..., capturable=True)")
+        self.params, self.dataset, self.opt = params, dataset, optimizer
+        dev = params['means3D'].device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedViews runs on the GPU only")
+        leaves = [g["params"][0] for g in optimizer.param_groups]
+        # the warm-up below takes real optimisation steps; everything it touches is restored before the captures
+        snap_p = [p.detach().clone() for p in leaves]
+        prev_mode = R.get_sync_mode()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            R.set_sync_mode("checked")
+            for data in dataset:                                   # learns the pair-arena capacity of every camera
+                l, _, _ = photometric_iteration(params, data, fused_loss, extra_loss)
+                l.backward()
+                with torch.no_grad():
+                    optimizer.step()
+                    optimizer.zero_grad(set_to_none=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for p, s0 in zip(leaves, snap_p):
+                p.copy_(s0)
+            for p in leaves:
+                st = optimizer.state.get(p)
+                if st is not None and "exp_avg" in st:
+                    st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"] = 0
+            optimizer._hyper(dev)[0].zero_()
+        optimizer.sync_hyper()
+        self.graphs, self.losses, self.radii = [], [], []
+        # binning status words (overflow flag, pairs needed) of every captured forward, copied out INSIDE its graph: the
+        # graphs share one memory pool, so a state buffer is only meaningful until the next graph replays
+        self._status = torch.zeros(len(dataset), 4, dtype=torch.int32, device=dev)
+        self._caps = []
+        R.set_sync_mode("lazy")
+        try:
+            with warnings.catch_warnings():
+                # the warm-up ran on a side stream, the captures run on torch's capture stream: torch points that out for
+                # every AccumulateGrad node; both orders are synchronised above, so the hint does not apply
+                warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
+                self._capture_all(R, fused_loss, extra_loss)
+        finally:
+            R._BATCH_LOG = None
+            R.set_sync_mode(prev_mode)
+        optimizer.zero_grad(set_to_none=True)
+
+    def _capture_all(self, R, fused_loss, extra_loss) -> None:
+        pool = None
+        for data in self.dataset:
+            self.opt.zero_grad(set_to_none=True)
+            R._BATCH_LOG = []
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                l, radius, _ = photometric_iteration(self.params, data, fused_loss, extra_loss)
+                batch = R._BATCH_LOG[-1]
+                self._status[len(self.graphs)].copy_(batch.state[:16].view(torch.int32))
+                l.backward()
+                self.opt.step()
+            pool = g.pool()
+            self.graphs.append(g)
+            self.losses.append(l.detach())
+            self.radii.append(radius)
+            self._caps.append(int(batch.prob.pair_capacity))
+
+    def step(self, index: int) -> torch.Tensor:
+        """Replay the iteration of camera `index`; returns its loss (a device scalar that the next replay of the same camera
+        overwrites)."""
+        self.opt.sync_hyper()
+        self.graphs[index].replay()
+        return self.losses[index]
+
+    def check(self) -> None:
+        """Synchronising read of every captured forward's binning status: raises if a replay was truncated."""
+        for i, (overflow, need, _, _) in enumerate(self._status.tolist()):
+            if overflow:
+                raise RuntimeError(f"the graphed render of camera {i} needed {need} (Gaussian,tile) pairs per view, its recorded arena "
+                                   f"holds {self._caps[i]}; build a new GraphedViews on the current scene")

@@ -18,7 +18,8 @@ from . import _lib
 
 
 class FusedAdamPins:
-    def __init__(self, param_groups: List[dict], lr: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-15):
+    def __init__(self, param_groups: List[dict], lr: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-15,
+                 capturable: bool = False):
         if len(param_groups) > _lib.T4D_ADAM_MAX_TENSORS:
             raise ValueError(f"at most {_lib.T4D_ADAM_MAX_TENSORS} tensors per fused step")
         self.param_groups = []
@@ -32,6 +33,34 @@ class FusedAdamPins:
         self.betas, self.eps = betas, eps
         self.state: Dict[torch.Tensor, dict] = {}
         self._pins: Dict[str, tuple] = {}
+        # capturable: step counts and learning rates live in device memory (t4d_adam_pin_step_graph), so that step() can be
+        # recorded in a HIP graph and replayed (loop.GraphedViews); call sync_hyper() after changing a group's 'lr'
+        self.capturable = capturable
+        self._step_dev: Optional[torch.Tensor] = None
+        self._lr_dev: Optional[torch.Tensor] = None
+        self._lr_host: Optional[List[float]] = None
+
+    def _hyper(self, dev):
+        if self._step_dev is None:
+            self._step_dev = torch.zeros(len(self.param_groups), dtype=torch.int32, device=dev)
+            self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+        return self._step_dev, self._lr_dev
+
+    def sync_hyper(self) -> None:
+        """Push the groups' learning rates to the device copy the captured step reads (no-op when nothing changed)."""
+        if not self.capturable:
+            return
+        lrs = [float(g["lr"]) for g in self.param_groups]
+        if lrs != self._lr_host:
+            _, lr_dev = self._hyper(self.param_groups[0]["params"][0].device)
+            lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            self._lr_host = lrs
+
+    def steps(self) -> List[int]:
+        """Per-tensor step counts (synchronising read in capturable mode)."""
+        if self.capturable and self._step_dev is not None:
+            return [int(x) for x in self._step_dev.tolist()]
+        return [int(self.state.get(g["params"][0], {}).get("step", 0)) for g in self.param_groups]
 
     # -- pins ------------------------------------------------------------------------------------------------
     def set_pin(self, name: str, index, values) -> None:
@@ -118,7 +147,15 @@ class FusedAdamPins:
             arr[k] = _lib.T4DAdamTensor(ptr(p), ptr(grad), ptr(st.get("exp_avg")) if grad is not None else None,
                                         ptr(st.get("exp_avg_sq")) if grad is not None else None, ptr(mask), ptr(vals), rows,
                                         width, float(g["lr"]), int(st.get("step", 0)) if grad is not None else 0, 0)
-        rc = lib.t4d_adam_pin_step(arr, len(self.param_groups), float(self.betas[0]), float(self.betas[1]),
-                                   float(self.eps), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if self.capturable:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper()
+            step_dev, lr_dev = self._hyper(dev)
+            rc = lib.t4d_adam_pin_step_graph(arr, len(self.param_groups), float(self.betas[0]), float(self.betas[1]),
+                                             float(self.eps), C.c_void_p(step_dev.data_ptr()), C.c_void_p(lr_dev.data_ptr()), stream)
+        else:
+            rc = lib.t4d_adam_pin_step(arr, len(self.param_groups), float(self.betas[0]), float(self.betas[1]),
+                                       float(self.eps), stream)
         if rc != 0:
             raise RuntimeError(f"t4d_adam_pin_step failed (code {rc}): {_lib.last_error()}")

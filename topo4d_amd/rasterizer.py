@@ -51,6 +51,8 @@ class GaussianRasterizationSettings(NamedTuple):
 _SYNC_MODE = "checked"
 _CAPACITY = {}          # (device_index, P, H, W) -> learned per-view pair capacity
 _AUTO = {}              # (device_index, P, H, W, views key) -> _AutoTrack of the "auto" sync mode
+_BATCH_LOG = None       # when a list: every ViewBatch that runs a forward is appended (loop.GraphedViews keeps the batches
+                        # of its captures to read their overflow flags back later)
 
 
 class _AutoTrack:
@@ -333,6 +335,8 @@ class ViewBatch:
         elif track is not None:
             track.mark(torch.cuda.current_stream(dev), cap)
         self.prob, self.state, self.radii = prob, state, radii
+        if _BATCH_LOG is not None:
+            _BATCH_LOG.append(self)
         self.inputs = (means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs)
         self.last_status = status if checked else None
         return color, radii, depth, alpha
