@@ -51,6 +51,7 @@ class GaussianRasterizationSettings(NamedTuple):
 _SYNC_MODE = "checked"
 _CAPACITY = {}          # (device_index, P, H, W) -> learned per-view pair capacity
 _AUTO = {}              # (device_index, P, H, W, views key) -> _AutoTrack of the "auto" sync mode
+_AUTO_MAX = 256         # camera sets tracked at a time
 _BATCH_LOG = None       # when a list: every ViewBatch that runs a forward is appended (loop.GraphedViews keeps the batches
                         # of its captures to read their overflow flags back later)
 
@@ -287,6 +288,9 @@ class ViewBatch:
             akey = key + (self.cam_key,)
             track = _AUTO.get(akey)
             if track is None:
+                if len(_AUTO) >= _AUTO_MAX:                       # Topo4D builds new camera tuples every frame (train.py:98):
+                    for old in list(_AUTO)[: _AUTO_MAX // 2]:     # forget the oldest half (dicts keep insertion order)
+                        del _AUTO[old]
                 track = _AUTO[akey] = _AutoTrack()
                 checked = True                                    # first time these cameras see this scene size
             else:
