@@ -105,3 +105,16 @@ def test_scene_generator_is_seeded_and_matches_reference_recipe():
     rv = boundary.params2rendervar(a)
     assert torch.allclose(rv["rotations"].norm(dim=1), torch.ones(600), atol=1e-6)
     assert scene.CONFIGS["C2"] == dict(n_lat=150, n_lon=200, H=512, W=512, n_views=24, sh_degree=None)
+
+
+def test_graphed_views_argument_checks_need_no_gpu():
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    p = {"means3D": torch.nn.Parameter(torch.zeros(4, 3))}
+    groups = [{"params": [p["means3D"]], "name": "means3D", "lr": 1e-3}]
+    with pytest.raises(ValueError, match="capturable"):
+        loop.GraphedViews(p, [], FusedAdamPins(groups))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        loop.GraphedViews(p, [], FusedAdamPins(groups, capturable=True))
+    opt = FusedAdamPins(groups, capturable=True)
+    assert opt.steps() == [0]
