@@ -77,3 +77,32 @@ def _worker_async(rank, world, port):
 
 def test_async_gather_world2_gloo():
     mp.spawn(_worker_async, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_band_bounds_partition_the_rows():
+    for n_rows, world in ((8192, 8), (1024, 3), (7, 8), (5, 1)):
+        bounds = [t4d_dist.band_bounds(n_rows, r, world) for r in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == n_rows
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+        heights = [b - a for a, b in bounds]
+        assert max(heights) - min(heights) <= 1
+    with pytest.raises(ValueError):
+        t4d_dist.band_bounds(10, 2, 2)
+
+
+def _worker_bands(rank, world, port, n_rows):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(n_rows * 4 * 3, dtype=torch.float32).reshape(n_rows, 4, 3)      # what a 1-GPU bake would produce
+        b0, b1 = t4d_dist.band_bounds(n_rows, rank, world)
+        got = t4d_dist.gather_bands(full[b0:b1].contiguous(), n_rows)                       # texture.bake_texture_sharded's exchange
+        assert torch.equal(got, full), rank
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [16, 7])
+def test_gather_bands_world2_gloo(n_rows):
+    mp.spawn(_worker_bands, args=(2, _free_port(), n_rows), nprocs=2, join=True)

@@ -90,3 +90,38 @@ def test_dense_attribute_interpolation_bit_exact_vs_reference_golden():
     v2 = {"dense_vertex_father": father, "dense_vertex_weight": w, "dense_quad_faces": quads, "dense_vertex": ref}
     out = texture.compute_vertex_attribute_by_weight(v2, torch.tensor(attr).cuda())
     np.testing.assert_array_equal(out.cpu().numpy(), ref.astype(np.float32))
+
+
+def _sharded_bake_worker(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    from topo4d_amd import texture
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share cuda:0 in this test
+    try:
+        rng = np.random.default_rng(7)
+        n, res = 40, 250
+        uvs = rng.uniform(0.02, 0.98, size=(n * n, 2)).astype(np.float32)
+        colors = rng.uniform(size=(n * n, 3)).astype(np.float32)
+        idx = np.arange(n * n).reshape(n, n)
+        faces = np.concatenate([np.stack([idx[:-1, :-1], idx[1:, :-1], idx[:-1, 1:]], -1).reshape(-1, 3),
+                                np.stack([idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]], -1).reshape(-1, 3)]).astype(np.int32)
+        img = texture.bake_texture_sharded(uvs, colors, faces, res)
+        if rank == 0:
+            np.save(out_path, img)
+            np.save(out_path + ".single.npy", texture.bake_texture(uvs, colors, faces, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_bake_two_ranks_equals_single_bake(tmp_path):
+    """BASELINE config 5's shard: every rank bakes a row band, the bands are all-gathered (gloo here, RCCL on a real node)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sharded.npy")
+    mp.spawn(_sharded_bake_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = np.load(out), np.load(out + ".single.npy")
+    assert a.shape == (250, 250, 3) and a.dtype == np.uint8 and a.any()
+    np.testing.assert_array_equal(a, b)

@@ -82,3 +82,34 @@ def all_reduce_grads(grads: Sequence[torch.Tensor]) -> None:
     for g in grads:
         g.copy_(flat[o: o + g.numel()].view_as(g))
         o += g.numel()
+
+
+def band_bounds(n_rows: int, rank: int, world: int):
+    """Contiguous row band [begin, end) of rank `rank` when `n_rows` image rows are split over `world` ranks (the first
+    n_rows % world ranks take one row more): the unit the texture bake (BASELINE config 5) shards by."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(n_rows, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def gather_bands(band: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """all_gather of per-rank row bands ([rows_r, ...], band_bounds order) into the full [n_rows, ...] tensor on every rank.
+    Bands may differ by one row; they are padded to the tallest for the collective."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return band
+    world = dist.get_world_size()
+    if band.is_cuda and dist.get_backend() != "nccl":         # gloo dry runs: stage through the host
+        return gather_bands(band.cpu(), n_rows).to(band.device)
+    tallest = -(-n_rows // world)
+    padded = torch.zeros((tallest,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
+    padded[: band.shape[0]] = band
+    out = torch.empty((world * tallest,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
+    dist.all_gather_into_tensor(out, padded.contiguous())
+    parts = []
+    for r in range(world):
+        b0, b1 = band_bounds(n_rows, r, world)
+        parts.append(out[r * tallest: r * tallest + (b1 - b0)])
+    return torch.cat(parts, 0)

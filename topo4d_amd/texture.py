@@ -90,6 +90,22 @@ def bake_texture(uvs, colors, faces, res: int = 1024, device="cuda") -> np.ndarr
     return (tex.cpu().numpy() * 255).astype(np.uint8)          # same numpy cast as helpers.py:959
 
 
+def bake_texture_sharded(uvs, colors, faces, res: int = 1024, device="cuda") -> np.ndarray:
+    """bake_texture with the rows of the UV image split over the ranks of the default process group (one process per GPU):
+    every rank bakes its own band (`render_colors(rows=...)`, the triangles that cannot touch the band are rejected by
+    the binning kernel), the bands are all-gathered, every rank returns the full uint8 image.  Byte-identical to
+    bake_texture: the per-texel result does not depend on the band it is computed in."""
+    import torch.distributed as dist
+    from . import dist as t4d_dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bake_texture(uvs, colors, faces, res, device)
+    r0, r1 = t4d_dist.band_bounds(res, dist.get_rank(), dist.get_world_size())
+    uv_coords = process_uv(uvs, res, res)
+    tex = render_colors(uv_coords, faces, colors, res, res, c=3, rows=(r0, r1), device=device)
+    full = t4d_dist.gather_bands(tex[r0:r1].contiguous(), res)
+    return (full.cpu().numpy() * 255).astype(np.uint8)
+
+
 def write_texture(path, uvs, colors, faces, res: int = 1024, device="cuda") -> None:
     """helpers.py:953-960 (`io.imsave` replaced by PIL, which this image has)."""
     from PIL import Image
