@@ -580,7 +580,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
         uint32_t fill = 0;                                  // fullest pair-slot segment of this view
         for (uint32_t k = 0; k < kp.nseg; k++) fill = max(fill, kp.view_cursor[v * kCursorSegs + k]);
         // capacity this view needs: every segment must hold the fullest one
-        atomicMax(&kp.status->max_pairs, max(total, fill * kp.nseg));
+        const unsigned long long need = max((unsigned long long)total, (unsigned long long)fill * kp.nseg);
+        atomicMax(&kp.status->max_pairs, (uint32_t)min(need, 0xffffffffull));
         atomicAdd(&kp.status->total_pairs, (unsigned long long)total);
         if (total > kp.cap || fill > kp.seg_cap) atomicOr(&kp.status->overflow, 1u);
     }
