@@ -75,9 +75,24 @@ def cpu_baseline(cfg, n_sample_views):
                             rv.get("colors_precomp"), rv.get("shs"))
         r.backward(dc[v])
     dt = time.perf_counter() - t0
-    return {"value": round(n_sample_views / dt, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_sample_views} of the {cfg['n_views']} views of the same scene, fwd+bwd, "
-                      f"oracle/raster_oracle.c -O3 -fopenmp ({os.cpu_count()} threads), {dt:.1f}s wall"}
+    out = {"value": round(n_sample_views / dt, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n_sample_views} of the {cfg['n_views']} views of the same scene, fwd+bwd, "
+                     f"oracle/raster_oracle.c -O3 -fopenmp ({os.cpu_count()} threads), {dt:.1f}s wall"}
+    # the same code on ONE host thread, one view (SURVEY.md 8d asks for both figures)
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        t1 = time.perf_counter()
+        r = CO.OracleRender(cams[0], rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                            rv.get("colors_precomp"), rv.get("shs"))
+        r.backward(dc[0])
+        d1 = time.perf_counter() - t1
+        gomp.omp_set_num_threads(os.cpu_count())
+        out["one_thread"] = {"value": round(1.0 / d1, 4), "unit": "views/s", "cores": 1, "sample": f"1 view, {d1:.1f}s wall"}
+    except Exception as e:                       # libgomp not loadable: report the multi-threaded figure only
+        out["one_thread"] = None
+    return out
 
 
 def main():
