@@ -43,7 +43,9 @@ for v in range(2):
         if n > 1:
             k = s["keys"][v, off:off + n]
             assert np.all(k[1:] > k[:-1]), (v, t)
-print("longest tile list", int(s["tile_count"].max()))
+tc = s["tile_count"].ravel()
+print("longest tile list", int(tc.max()), "; tiles > 512:", int((tc > 512).sum()), " > 2048:", int((tc > 2048).sum()), " > 4096:", int((tc > 4096).sum()),
+      "; keys in tiles > 2048:", int(tc[tc > 2048].sum()), "of", int(tc.sum()), "; non-empty tiles", int((tc > 0).sum()))
 # determinism + timing
 b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv["colors_precomp"]); g2 = b.backward(dc)
 for k in g1:

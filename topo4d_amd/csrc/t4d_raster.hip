@@ -23,7 +23,8 @@
 //   k_scan_tiles      A.2  per view: exclusive scan of tile counts -> tile offsets, overflow status, length buckets
 //   k_scatter         A.2  per (view,Gaussian): key -> tile_off + rank (no atomics); tail blocks build the work items
 //   k_sort_tiles      A.2  per work item: sort the bin by (depth bits, index): runs of 64 sorted in registers, merged by
-//                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS); global bitonic beyond
+//                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS; beyond: LDS-sorted chunks merged
+//                          level by level in global memory)
 //   k_render_fwd      A.3  per work item: 256 threads = 4 wave64 = 16 DPP rows, one 4x4 sub-block each; front-to-back blend
 //   k_render_bwd      A.4  per work item: back-to-front replay, row-local reduction, one record per pair
 //   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D/SH chain rule
@@ -80,7 +81,7 @@ std::vector<ProfRec> g_prof;
 // ---------------------------------------------------------------------------------------------------------
 struct Layout {
     size_t status, view_total, view_cursor, tile_count, bucket_fill, zero_end;
-    size_t tile_off, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, final_T, n_contrib, total;
+    size_t tile_off, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, sort_tmp, final_T, n_contrib, total;
 };
 
 struct DevStatus {            // first bytes of the state buffer
@@ -116,6 +117,7 @@ Layout make_layout(const T4DProblem &p)
     L.pair_off = o;      o = align_up(o + V * P * 4);
     L.pair_rank = o;     o = align_up(o + V * cap * 4);
     L.keys = o;          o = align_up(o + V * cap * 8);
+    L.sort_tmp = o;      o = align_up(o + V * cap * 8);
     L.final_T = o;       o = align_up(o + V * HW * 4);
     L.n_contrib = o;     o = align_up(o + V * HW * 4);
     L.total = o;
@@ -140,7 +142,7 @@ struct KP {
     float4 *conic_opacity;
     float *rgb;
     uint8_t *clamped;
-    unsigned long long *keys;
+    unsigned long long *keys, *sort_tmp;       // sort_tmp: ping-pong arena for bins longer than the LDS sort buffer
     float *final_T;
     uint32_t *n_contrib;
     // forward outputs
@@ -631,40 +633,8 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// A.2 per-tile sort by (depth bits, Gaussian index): all-ascending bitonic network for arbitrary n
+// A.2 per-tile sort by (depth bits, Gaussian index)
 // ---------------------------------------------------------------------------------------------------------
-template <typename Ptr>
-__device__ __forceinline__ void bitonic_any_n(Ptr a, const uint32_t n, const int tid)
-{
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const uint32_t half = np2 >> 1;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        // flip stage: i <-> block_end - 1 - (i - block_start)
-        for (uint32_t p = tid; p < half; p += kBlock) {
-            const uint32_t hb = k >> 1;
-            const uint32_t o = p & (hb - 1), blk2 = (p - o) << 1;      // blk * k  (hb is a power of two)
-            const uint32_t i = blk2 + o, j = blk2 + k - 1 - o;
-            if (j < n) {
-                const unsigned long long x = a[i], y = a[j];
-                if (x > y) { a[i] = y; a[j] = x; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t s = k >> 2; s > 0; s >>= 1) {
-            for (uint32_t p = tid; p < half; p += kBlock) {
-                const uint32_t i = ((p & ~(s - 1)) << 1) | (p & (s - 1));
-                const uint32_t j = i | s;
-                if (j < n) {
-                    const unsigned long long x = a[i], y = a[j];
-                    if (x > y) { a[i] = y; a[j] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // Sort the 64 keys of a wave (one per lane) ascending, entirely in registers: bitonic network whose exchanges are DPP
 // moves (xor 1, 2: quad_perm; xor 4: two bank-masked row shifts; xor 8: row_ror:8) or ds_bpermute (xor 16, 32).
 template <int J>
@@ -709,6 +679,60 @@ __device__ __forceinline__ uint32_t run_lower_bound(const unsigned long long *ru
     return pos + (run[pos] < key ? 1u : 0u);
 }
 
+// Sort n <= kSortLdsCap keys (global memory, in place) through the workgroup's LDS buffer: runs of 64 are sorted in
+// registers, then at every level each key finds its slot in the merged pair of runs as (position in its own run) + (keys of
+// the sibling run below it), log2(width)+1 dependent LDS reads; keys wait in registers between the read and the write phase.
+// log2(n/64) levels with two barriers each (a compare-exchange network needs ~60 barriers at this size).
+__device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const uint32_t n, unsigned long long *s_keys,
+                                               const int tid, const int wave, const int lane)
+{
+    constexpr int kPer = kSortLdsCap / kBlock;
+    const uint32_t runs = (n + 63u) >> 6, N = runs << 6;
+    for (uint32_t r = (uint32_t)wave; r < runs; r += 4) {
+        const uint32_t i = (r << 6) + (uint32_t)lane;
+        unsigned long long k0 = i < n ? keys[i] : ~0ull;           // the last run is padded with +inf
+        wave_sort64(k0, lane);
+        s_keys[i] = k0;
+    }
+    __syncthreads();
+    for (uint32_t w = 64; w < N; w <<= 1) {
+        unsigned long long kk[kPer];
+        uint32_t np[kPer];
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const uint32_t p = (uint32_t)tid + e * kBlock;
+            if (p < N) {
+                kk[e] = s_keys[p];
+                const uint32_t run = p / w, sbase = (run ^ 1u) * w;
+                const uint32_t slen = sbase < N ? min(w, N - sbase) : 0u;
+                const unsigned long long *sib = s_keys + sbase;
+                uint32_t pos = 0;
+                for (uint32_t st = w >> 1; st > 0; st >>= 1)
+                    if (pos + st <= slen && sib[pos + st - 1] < kk[e]) pos += st;
+                if (pos < slen && sib[pos] < kk[e]) pos++;
+                np[e] = (run & ~1u) * w + (p & (w - 1u)) + pos;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer; e++)
+            if ((uint32_t)tid + e * kBlock < N) s_keys[np[e]] = kk[e];
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
+    __syncthreads();
+}
+
+// number of keys smaller than `key` among run[0..len) (sorted, global memory)
+__device__ __forceinline__ uint32_t lower_bound_global(const unsigned long long *run, const uint32_t len, const uint32_t cap2,
+                                                       const unsigned long long key)
+{
+    uint32_t pos = 0;
+    for (uint32_t st = cap2 >> 1; st > 0; st >>= 1)                  // cap2 = power of two >= len
+        if (pos + st <= len && run[pos + st - 1] < key) pos += st;
+    return pos + ((pos < len && run[pos] < key) ? 1u : 0u);
+}
+
 __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 {
     __shared__ unsigned long long s_keys[kSortLdsCap];
@@ -749,48 +773,39 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
                 }
             }
         } else if (n <= (uint32_t)kSortLdsCap) {
-            // Merge sort by ranking, in place: runs of 64 are sorted in registers, then at every level each key finds
-            // its slot in the merged pair of runs as (position in its own run) + (keys of the sibling run below it),
-            // log2(width)+1 dependent LDS reads; keys wait in registers between the read and the write phase.
-            // log2(n/64) levels with two barriers each (the compare-exchange network needs ~60 barriers at this size).
-            constexpr int kPer = kSortLdsCap / kBlock;
-            const uint32_t runs = (n + 63u) >> 6, N = runs << 6;
-            for (uint32_t r = (uint32_t)wave; r < runs; r += 4) {
-                const uint32_t i = (r << 6) + (uint32_t)lane;
-                unsigned long long k0 = i < n ? keys[i] : ~0ull;
-                wave_sort64(k0, lane);
-                s_keys[i] = k0;
-            }
-            __syncthreads();
-            for (uint32_t w = 64; w < N; w <<= 1) {
-                unsigned long long kk[kPer];
-                uint32_t np[kPer];
-#pragma unroll
-                for (int e = 0; e < kPer; e++) {
-                    const uint32_t p = (uint32_t)tid + e * kBlock;
-                    if (p < N) {
-                        kk[e] = s_keys[p];
-                        const uint32_t run = p / w, sbase = (run ^ 1u) * w;
-                        const uint32_t slen = sbase < N ? min(w, N - sbase) : 0u;
-                        const unsigned long long *sib = s_keys + sbase;
-                        uint32_t pos = 0;
-                        for (uint32_t st = w >> 1; st > 0; st >>= 1)
-                            if (pos + st <= slen && sib[pos + st - 1] < kk[e]) pos += st;
-                        if (pos < slen && sib[pos] < kk[e]) pos++;
-                        np[e] = (run & ~1u) * w + (p & (w - 1u)) + pos;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < kPer; e++)
-                    if ((uint32_t)tid + e * kBlock < N) s_keys[np[e]] = kk[e];
-                __syncthreads();
-            }
-            for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
+            sort_chunk_lds(keys, n, s_keys, tid, wave, lane);
         } else {
-            // rare: a bin longer than the LDS buffer is sorted in place in global memory by this workgroup
-            // (same network; __syncthreads() orders the workgroup's own global accesses through its CU's L1/L2)
-            bitonic_any_n(keys, n, tid);
+            // A bin longer than the LDS buffer (dense passes: ~100 of 22,000 bins at P = 1M, 4096x3008): chunks of kSortLdsCap
+            // keys are sorted through the LDS, then merged level by level IN GLOBAL MEMORY by the same ranking step, ping-pong
+            // between the key arena and the scratch arena of the same size (the bin's keys stay in this XCD's L2).  Four
+            // independent binary searches per thread and step overlap their latencies.
+            for (uint32_t c = 0; c < n; c += kSortLdsCap) sort_chunk_lds(keys + c, min((uint32_t)kSortLdsCap, n - c), s_keys, tid, wave, lane);
+            unsigned long long *src = keys, *dst = kp.sort_tmp + (size_t)v * kp.cap + off;
+            for (uint32_t w = kSortLdsCap; w < n; w <<= 1) {
+                __threadfence_block();
+                __syncthreads();                                   // the previous level's writes are visible to the workgroup
+                for (uint32_t i0 = (uint32_t)tid * 4u; i0 < n; i0 += kBlock * 4u) {
+                    unsigned long long kk[4];
+                    uint32_t slot[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) kk[e] = i0 + e < n ? src[i0 + e] : ~0ull;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t i = i0 + e, run = i / w, sbase = (run ^ 1u) * w;
+                        const uint32_t slen = sbase < n ? min(w, n - sbase) : 0u;
+                        slot[e] = (run & ~1u) * w + (i & (w - 1u)) + lower_bound_global(src + sbase, slen, w, kk[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (i0 + e < n) dst[slot[e]] = kk[e];
+                }
+                unsigned long long *t2 = src; src = dst; dst = t2;
+            }
+            if (src != keys) {
+                __threadfence_block();
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += kBlock) keys[i] = src[i];
+            }
         }
         __syncthreads();                                           // s_keys is reused by the next item
     }
@@ -1781,6 +1796,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.rgb = reinterpret_cast<float *>(st + L.rgb);
     kp.clamped = reinterpret_cast<uint8_t *>(st + L.clamped);
     kp.keys = reinterpret_cast<unsigned long long *>(st + L.keys);
+    kp.sort_tmp = reinterpret_cast<unsigned long long *>(st + L.sort_tmp);
     kp.final_T = reinterpret_cast<float *>(st + L.final_T);
     kp.n_contrib = reinterpret_cast<uint32_t *>(st + L.n_contrib);
 }
