@@ -131,7 +131,9 @@ size_t t4d_backward_scratch_bytes(const T4DProblem *prob);
  * filled only in CHECKED / DEBUG_SYNC mode (otherwise use t4d_fetch_status after the stream has drained). */
 int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO *io, T4DStatus *status, void *hip_stream);
 
-/* Backward: per-tile back-to-front replay (atomic-free, deterministic) -> per-Gaussian gather + chain rule. */
+/* Backward: per-tile back-to-front replay (atomic-free, deterministic) -> per-Gaussian gather + chain rule.
+ * If the forward that produced `state` overflowed its pair arena (only possible without T4D_FLAG_CHECKED), every
+ * gradient of this call is written as ZERO: a truncated pass never yields garbage. */
 int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardIO *io, void *hip_stream);
 
 /* Copies the status block of a forward's state buffer to the host (synchronises the stream). */
@@ -230,7 +232,7 @@ int t4d_profile_begin(void);
 int t4d_profile_end(T4DKernelTime *out, int max_entries, int *n_entries);
 
 /* Test/debug only: byte offsets of the arrays inside a state buffer, in this order:
- *   status, view_total, view_cursor, tile_count, tile_cursor, tile_off, xy, depth, conic_opacity, rgb, clamped,
+ *   status, view_total, view_cursor, tile_count, bucket_fill, tile_off, xy, depth, conic_opacity, rgb, clamped,
  *   pair_off, keys, final_T, n_contrib, total_bytes.
  * The layout is NOT part of the stable ABI; tests use it to check the integer state (tile bins, sort order,
  * n_contrib) bit-for-bit against the oracle. */

@@ -23,8 +23,9 @@ autograd returns what the CUDA library returns:
   * when the EWA frustum clamp (±1.3·tanfov) is active, the clamped coordinate is treated as a
     constant (its gradient is dropped);
   * quaternions are used un-normalised (Topo4D normalises outside, helpers.py:95).
-One deviation is NOT reproduced: the conic backward of the library divides by (det²+1e-7)
-instead of det²; with the +0.3 dilation det >= 0.09, so the relative difference is <= 1.3e-5.
+  * the conic backward divides by (det² + 1e-7) instead of det² (`_ConicOfCov2D.backward`, the same
+    expression as oracle/raster_oracle.c and the kernels; with the +0.3 dilation det >= 0.09, so the
+    difference from exact calculus is <= 1.3e-5 relative).
 """
 from __future__ import annotations
 
@@ -52,6 +53,27 @@ def _load_constants():
 C = _load_constants()
 TILE = int(C["T4D_TILE_X"])
 assert TILE == int(C["T4D_TILE_Y"]) == 16
+
+
+class _ConicOfCov2D(torch.autograd.Function):
+    """conic = (c, -b, a) / det of the dilated 2D covariance [[a, b], [b, c]].  The published library's backward
+     multiplies by 1 / (det² + 1e-7) where calculus has 1 / det²; restated here so that
+    autograd returns what the library returns."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, det_safe):
+        ctx.save_for_backward(a, b, c, det_safe)
+        return torch.stack([c / det_safe, -b / det_safe, a / det_safe], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, c, det = ctx.saved_tensors
+        X, Y, Z = g[:, 0], g[:, 1], g[:, 2]              # dL/d(conic A, B, C)
+        d2inv = 1.0 / (det * det + C["T4D_CONIC_BWD_EPS"])
+        da = d2inv * (-c * c * X + b * c * Y + (det - a * c) * Z)
+        dc = d2inv * (-a * a * Z + a * b * Y + (det - a * c) * X)
+        db = d2inv * (2.0 * b * c * X - (det + 2.0 * b * b) * Y + 2.0 * a * b * Z)
+        return da, db, dc, None
 
 
 class View(NamedTuple):
@@ -153,7 +175,7 @@ def preprocess(view: View, means3D, means2D, opacities, shs, colors_precomp, sca
     det = a * c_ - b * b
     valid = valid & (det != 0)
     det_safe = torch.where(det != 0, det, torch.ones_like(det))
-    conic = torch.stack([c_ / det_safe, -b / det_safe, a / det_safe], dim=1)
+    conic = _ConicOfCov2D.apply(a, b, c_, det_safe.detach())
     mid = 0.5 * (a + c_)
     lam1 = mid + torch.sqrt(torch.clamp(mid * mid - det, min=C["T4D_EIGEN_FLOOR"]))
     lam2 = mid - torch.sqrt(torch.clamp(mid * mid - det, min=C["T4D_EIGEN_FLOOR"]))

@@ -85,6 +85,10 @@ def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypa
         st = batch2.fetch_status()
         assert st.overflow == 1 and st.max_pairs_per_view > 512
         assert np.isfinite(out2["color"]).all()
+        # a truncated forward's backward is benign: every gradient is exactly zero (never sums over unwritten scratch)
+        for k, v in g2.items():
+            if v is not None:
+                assert not v.any(), k
     finally:
         topo4d_amd.set_sync_mode("checked")
         rasterizer._CAPACITY.clear()
@@ -242,7 +246,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
     call = lambda r, sc=1.0: r(d["means3D"], None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * sc,
                                rotations=d["rotations"])
     ref = [[t.clone() for t in call(r)] for r in R]
-    rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear()
+    rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()
     topo4d_amd.set_sync_mode("auto")
     try:
         for it in range(4):                                   # first call per camera is checked, the rest are not
@@ -268,7 +272,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
         for a, b in zip(out, chk):
             assert torch.equal(a, b)
         # an abrupt jump (scales x6 from one call to the next) overflows once and is REPORTED at the following call
-        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear()
+        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()
         call(R[0]); call(R[0])
         call(R[0], 6.0)
         torch.cuda.synchronize()
@@ -280,4 +284,4 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
             assert torch.equal(a, b)
     finally:
         topo4d_amd.set_sync_mode("checked")
-        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear()
+        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()

@@ -83,7 +83,7 @@ def decode_state(batch):
     has_sh = batch.inputs[6] is not None
     rc = lib.t4d_debug_state_layout(C.byref(prob), int(has_sh), offs, 16)
     assert rc == 0
-    names = ["status", "view_total", "view_cursor", "tile_count", "tile_cursor", "tile_off", "xy", "depth",
+    names = ["status", "view_total", "view_cursor", "tile_count", "bucket_fill", "tile_off", "xy", "depth",
              "conic_opacity", "rgb", "clamped", "pair_off", "keys", "final_T", "n_contrib", "total"]
     o = dict(zip(names, [int(x) for x in offs]))
     raw = batch.state.cpu().numpy()

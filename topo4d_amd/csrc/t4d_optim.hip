@@ -43,6 +43,7 @@ __global__ void k_adam_tick(int32_t *step_dev, const uint32_t has_grad_mask, con
 template <bool DEV>
 __global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
 {
+#pragma clang fp contract(off)      // only the two explicit fmaf below fuse (torch's lerp / addcmul forms); nothing else may
     int k = 0;
 #pragma unroll
     for (int i = 1; i < kMaxTensors; i++) k += (i < A.n && (long long)blockIdx.x >= A.first_block[i]) ? 1 : 0;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void k_dense_interp(const float *attr, const i
                                                       const double *weight, long long n_coarse, long long n_dense, int width,
                                                       float *out)
 {
+#pragma clang fp contract(off)      // numpy rounds every product and every partial sum: no fused multiply-adds here
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (n_coarse + n_dense) * width;
     if (i >= total) return;

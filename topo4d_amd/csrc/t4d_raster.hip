@@ -510,9 +510,10 @@ __device__ __forceinline__ int count_bucket(const uint32_t c)
     return (kBuckets - 2) - min(kBuckets - 2, 31 - __clz((int)c));
 }
 
-// Per-tile kernels are PERSISTENT: a fixed grid of (CUs x resident workgroups) loops over the length-ordered tile
-// list, item b -> workgroup b % gridDim.x.  Heavy tiles start first and consecutive heavy tiles land on different
-// XCDs (block b runs on XCD b % 8); empty tiles cost no workgroup launch and no dependent-load chain.
+// Per-tile kernels walk the length-ordered tile list with a grid-stride loop (grid size: tile_grid() on the host; a
+// fully resident grid was measured slower than the hardware dispatcher's dynamic balancing and is only kept behind
+// T4D_PERSISTENT=1).  Heavy tiles start first and consecutive heavy tiles land on different XCDs (block b runs on XCD
+// b % 8); empty tiles sit at the end of the list and end the loop.
 struct TileOrder {
     uint32_t pre[kBuckets + 1];     // exclusive prefix of the bucket totals (wave-uniform, lives in SGPRs)
 };
@@ -1422,7 +1423,10 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
     const size_t vg = (size_t)v * kp.P + g;
     const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
     const float *view = vr, *proj = vr + 16;
-    const int radius = kp.radii[vg];
+    // A forward whose pair arena overflowed (possible only without T4D_FLAG_CHECKED) left tile lists truncated and pair
+    // records unwritten: its backward returns ZERO gradients for every view instead of sums over uninitialised scratch.
+    const bool truncated = kp.status->overflow != 0u;
+    const int radius = truncated ? 0 : kp.radii[vg];
 
     float gm[3] = { 0.f, 0.f, 0.f }, g2x = 0.f, g2y = 0.f, gop = 0.f;
     float grgb[3] = { 0.f, 0.f, 0.f }, gsc[3] = { 0.f, 0.f, 0.f }, gq[4] = { 0.f, 0.f, 0.f, 0.f };

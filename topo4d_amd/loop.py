@@ -128,6 +128,9 @@ class GraphedViews:
             optimizer._hyper(dev)[0].zero_()
         optimizer.sync_hyper()
         self.graphs, self.losses, self.radii = [], [], []
+        # every tensor a captured kernel reads through a raw pointer must outlive the graphs: the packed camera records are
+        # otherwise owned only by the rasterizer's (evicting) view cache
+        self._keep = []
         # binning status words (overflow flag, pairs needed) of every captured forward, copied out INSIDE its graph: the
         # graphs share one memory pool, so a state buffer is only meaningful until the next graph replays
         self._status = torch.zeros(len(dataset), 4, dtype=torch.int32, device=dev)
@@ -153,6 +156,7 @@ class GraphedViews:
             with torch.cuda.graph(g, pool=pool):
                 l, radius, _ = photometric_iteration(self.params, data, fused_loss, extra_loss)
                 batch = R._BATCH_LOG[-1]
+                self._keep.append(batch.views)
                 self._status[len(self.graphs)].copy_(batch.state[:16].view(torch.int32))
                 l.backward()
                 self.opt.step()

@@ -18,6 +18,7 @@ csrc/t4d_raster.hip behind include/topo4d_raster.h.  There is no CPU path: CPU t
 from __future__ import annotations
 
 import ctypes as C
+from collections import OrderedDict
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
@@ -60,9 +61,10 @@ class _AutoTrack:
     """Bookkeeping of the "auto" sync mode for one (scene size, camera set): a ring of pinned status blocks, one per
     un-synchronised forward still in flight, each with the event that says it has landed, and the largest need seen."""
     RING = 8
-    __slots__ = ("pinned", "host", "events", "caps", "head", "count", "need")
+    __slots__ = ("pinned", "host", "events", "caps", "head", "count", "need", "key")
 
-    def __init__(self):
+    def __init__(self, key=None):
+        self.key = key                                  # (device_index, P, H, W) whose capacity this track feeds
         self.pinned = torch.zeros(self.RING, 2, dtype=torch.int64).pin_memory()
         self.host = self.pinned.numpy()                 # same memory, cheap scalar reads
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
@@ -79,6 +81,7 @@ class _AutoTrack:
         self.caps[self.head] = cap
         self.head = (self.head + 1) % self.RING
         self.count += 1
+        _INFLIGHT[id(self)] = self
 
     def harvest(self):
         """Yields (overflow, need, capacity used) of every un-synchronised call whose status has landed, oldest first.
@@ -93,7 +96,33 @@ class _AutoTrack:
             raw = int(self.host[tail, 0])
             out.append((raw & 0xffffffff, (raw >> 32) & 0xffffffff, self.caps[tail]))
             self.count -= 1
+        if not self.count:
+            _INFLIGHT.pop(id(self), None)
         return out
+
+
+_INFLIGHT = {}          # id(track) -> _AutoTrack with un-harvested status blocks
+
+
+def poll_truncation() -> None:
+    """"auto" sync mode: look at every binning status that has landed since the last look - of ALL camera sets, not only
+    the one being rendered - grow the arenas they ask for, and raise RuntimeError if any of those forwards was truncated
+    (its backward returned zero gradients, see t4d_rasterize_backward).  Every auto-mode forward calls this first; an
+    optimisation loop may also call it right before `optimizer.step()` to learn about a truncated pass as early as the GPU
+    allows.  Never synchronises unless a track's ring is full."""
+    truncated = None
+    for track in list(_INFLIGHT.values()):
+        for overflow, need, cap_used in track.harvest():
+            track.need = max(track.need, need)
+            if overflow:
+                truncated = (need, cap_used)
+                if track.key is not None:
+                    _CAPACITY[track.key] = max(_CAPACITY.get(track.key, 0), _round_capacity(track.need))
+    if truncated is not None:
+        raise RuntimeError(
+            f"topo4d_amd (sync_mode='auto'): an earlier render needed {truncated[0]} (Gaussian,tile) pairs per view but its "
+            f"arena held {truncated[1]}; it was truncated and its backward returned zero gradients. The arena has been "
+            "enlarged; re-run that iteration, or use set_sync_mode('checked') for scenes that change abruptly.")
 
 
 def set_sync_mode(mode: str) -> None:
@@ -103,10 +132,12 @@ def set_sync_mode(mode: str) -> None:
     calls is too small, and `ViewBatch.fetch_status()` / `last_status()` reports it.  Use lazy only when the
     capacity was established by a checked call on (nearly) the same scene — bench.py does.
     "auto": for optimisation loops.  The first forward of every (scene size, camera set) is checked; afterwards the
-    forward does not synchronise, the binning status is copied to pinned host memory asynchronously and inspected at a
-    later call with the same cameras (the next one if the GPU keeps up, at most 8 calls later if the host runs ahead): the arena is grown as soon as 75 % of it is in use (it is sized 1.5x the largest need
-    seen), so consecutive iterations of an optimiser cannot overflow it; should a previous call nevertheless have been
-    truncated (the scene jumped by more than a third between two calls), a RuntimeError says so."""
+    forward does not synchronise, the binning status is copied to pinned host memory asynchronously and inspected at the
+    next auto-mode forward of ANY camera set (`poll_truncation`; at most 8 calls of one camera set later if the host runs
+    ahead of the GPU): the arena is grown as soon as 75 % of it is in use (it is sized 1.5x the largest need seen), so
+    consecutive iterations of an optimiser cannot overflow it; should a previous call nevertheless have been truncated
+    (the scene jumped by more than a third between two calls), its backward returned zero gradients and a RuntimeError
+    says so at the next forward (or at an explicit `poll_truncation()` before `optimizer.step()`)."""
     global _SYNC_MODE
     if mode not in ("checked", "lazy", "auto"):
         raise ValueError("sync mode must be 'checked', 'lazy' or 'auto'")
@@ -129,7 +160,7 @@ def _round_capacity(n: int) -> int:
 # ------------------------------------------------------------------------------------------------------------
 # view records
 # ------------------------------------------------------------------------------------------------------------
-_VIEW_CACHE = {}
+_VIEW_CACHE = OrderedDict()   # id(settings) -> (settings, versions, packed record); least recently used first
 _VIEW_CACHE_MAX = 512
 
 
@@ -155,12 +186,16 @@ def pack_views(settings: Sequence[GaussianRasterizationSettings], device) -> tor
         ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, str(device))
         hit = _VIEW_CACHE.get(key)
         if hit is not None and hit[0] is s and hit[1] == ver:
+            _VIEW_CACHE.move_to_end(key)
             recs.append(hit[2])
             continue
         rec = _pack_one_view(s, device)
-        if len(_VIEW_CACHE) >= _VIEW_CACHE_MAX:
-            _VIEW_CACHE.clear()
         _VIEW_CACHE[key] = (s, ver, rec)
+        _VIEW_CACHE.move_to_end(key)
+        # evict the least recently used entries only: whoever still holds a record (a ViewBatch, a captured HIP graph via
+        # loop.GraphedViews) keeps its own reference, so eviction can never free memory a pending launch reads
+        while len(_VIEW_CACHE) > _VIEW_CACHE_MAX:
+            _VIEW_CACHE.popitem(last=False)
         recs.append(rec)
     if len(recs) == 1:
         out = recs[0].unsqueeze(0)                           # a view of the cached record: no kernel, no allocation
@@ -285,26 +320,17 @@ class ViewBatch:
         checked = (_SYNC_MODE == "checked") or self.debug or key not in _CAPACITY
         track = None
         if _SYNC_MODE == "auto" and not self.debug:
+            poll_truncation()                                     # statuses of every camera set that have landed by now
+            cap = _CAPACITY.get(key, cap)
             akey = key + (self.cam_key,)
             track = _AUTO.get(akey)
             if track is None:
                 if len(_AUTO) >= _AUTO_MAX:                       # Topo4D builds new camera tuples every frame (train.py:98):
                     for old in list(_AUTO)[: _AUTO_MAX // 2]:     # forget the oldest half (dicts keep insertion order)
                         del _AUTO[old]
-                track = _AUTO[akey] = _AutoTrack()
+                track = _AUTO[akey] = _AutoTrack(key)
                 checked = True                                    # first time these cameras see this scene size
             else:
-                truncated = None
-                for overflow, need, cap_used in track.harvest():
-                    track.need = max(track.need, need)
-                    if overflow:
-                        truncated = (need, cap_used)
-                if truncated is not None:
-                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), _round_capacity(track.need))
-                    raise RuntimeError(
-                        f"topo4d_amd (sync_mode='auto'): an earlier render of these cameras needed {truncated[0]} "
-                        f"(Gaussian,tile) pairs per view but its arena held {truncated[1]}; it was truncated. The arena has been "
-                        "enlarged; re-run that iteration, or use set_sync_mode('checked') for scenes that change abruptly.")
                 if track.need > 0.75 * cap:                       # grow well before the arena can overflow
                     cap = _round_capacity(track.need)
                     _CAPACITY[key] = max(_CAPACITY.get(key, 0), cap)
@@ -426,6 +452,11 @@ class _RasterizeViews(torch.autograd.Function):
             means3D, opacities, none_if_empty(scales), none_if_empty(rotations), none_if_empty(colors_precomp),
             none_if_empty(sh), none_if_empty(cov3Ds_precomp))
         ctx.batch = batch
+        # the backward kernels re-read the forward inputs: saving them through autograd (as upstream does) makes an in-place
+        # update between forward and backward raise instead of silently differentiating at the wrong point
+        ctx.input_slots = [i for i, t in enumerate(batch.inputs) if t is not None]
+        ctx.save_for_backward(*[batch.inputs[i] for i in ctx.input_slots])
+        batch.inputs = tuple(None if t is None else True for t in batch.inputs)     # ownership moved to the ctx
         ctx.set_materialize_grads(False)     # unused depth/alpha outputs arrive as None -> cheaper backward kernel
         ctx.mark_non_differentiable(radii)
         ctx.shapes = (means3D.shape, means2D.shape if means2D is not None else None, opacities.shape)
@@ -434,6 +465,10 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         batch: ViewBatch = ctx.batch
+        inputs = [None] * 7
+        for slot, t in zip(ctx.input_slots, ctx.saved_tensors):         # raises if one of them was modified in place
+            inputs[slot] = t
+        batch.inputs = tuple(inputs)
         if grad_color is None:
             grad_color = torch.zeros(batch.V, 3, batch.H, batch.W, dtype=torch.float32, device=batch.device)
         g = batch.backward(grad_color, grad_depth, grad_alpha)
