@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests import util
-from tests.test_gpu_parity import check_grads, check_outputs
+from tests.test_gpu_parity import check_grads, check_n_contrib, check_outputs
 
 pytestmark = pytest.mark.gpu
 
@@ -193,7 +193,7 @@ def test_c2_full_size_sampled_views_against_c_oracle(c2):
         assert int(c2["st"]["view_total"][v]) == r.num_rendered
         os_ = r.state()
         np.testing.assert_array_equal(c2["st"]["tile_count"][v], os_["ranges"][:, 1] - os_["ranges"][:, 0])
-        assert (c2["st"]["n_contrib"][v] == os_["n_contrib"]).mean() > 1 - 2e-4
+        check_n_contrib(c2["st"]["n_contrib"][v], os_["n_contrib"])
         check_outputs(c2["out"], r.color, r.depth, r.alpha, v)
         check_grads(c2["g"], gref, v)
 

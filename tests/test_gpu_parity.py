@@ -4,9 +4,10 @@ against the oracles on identical seeded inputs.
 
 Tolerances (fp32 kernels; north_star asks for gradient max-abs-error < 1e-4):
   * integer state (radii, tile bins, per-tile order, n_contrib): bit-exact against the C oracle;
-  * colour / depth / alpha: |err| <= OUT_TOL = 2e-5 for every pixel, except that at most FLIP_FRAC of the pixels may
-    differ by up to FLIP_MAX because a discrete test (alpha >= 1/255, T < 1e-4, power > 0) sits within 1 ulp of
-    its threshold and `expf` is not bit-identical between glibc and the device library;
+  * colour / depth / alpha: |err| <= OUT_TOL = 2e-5 for EVERY pixel of the seeded scenes (max_flips = 0).  Only the
+    randomised / adversarial cases pass an explicit max_flips > 0: there a discrete test (alpha >= 1/255, T < 1e-4,
+    power > 0) can sit within an ulp of its threshold, `expf` is not bit-identical between glibc and the device, and
+    a flipped pixel may then differ by up to FLIP_MAX;
   * gradients: max-abs-err <= GRAD_REL * max|reference gradient| (and < 1e-4 absolute), per tensor.
 """
 import numpy as np
@@ -18,19 +19,24 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 OUT_TOL = 2e-5
-FLIP_FRAC = 2e-4
 FLIP_MAX = 2e-2
 GRAD_REL = 2e-4
 GRAD_ABS = 1e-4
 
 
-def check_outputs(hip, ref_color, ref_depth, ref_alpha, v):
+def check_outputs(hip, ref_color, ref_depth, ref_alpha, v, max_flips=0):
+    """Every pixel within OUT_TOL; `max_flips` pixels (0 unless a test says otherwise) may be off by up to FLIP_MAX."""
     for name, a, b in (("color", hip["color"][v], ref_color), ("depth", hip["depth"][v], ref_depth),
                        ("alpha", hip["alpha"][v], ref_alpha)):
         err = np.abs(a.astype(np.float64) - np.asarray(b, np.float64).reshape(a.shape))
-        bad = err > OUT_TOL
-        assert bad.mean() <= FLIP_FRAC, f"{name}[view {v}]: {bad.mean():.2e} of pixels off by > {OUT_TOL} (max {err.max():.3e})"
+        bad = (err > OUT_TOL).reshape(err.shape[0], -1).any(axis=0)                  # per pixel, any channel
+        assert bad.sum() <= max_flips, f"{name}[view {v}]: {int(bad.sum())} pixels off by > {OUT_TOL} (max {err.max():.3e})"
         assert err.max() <= FLIP_MAX, f"{name}[view {v}]: max err {err.max():.3e}"
+
+
+def check_n_contrib(mine, ref, max_flips=0):
+    diff = int((np.asarray(mine) != np.asarray(ref)).sum())
+    assert diff <= max_flips, f"n_contrib differs on {diff} pixels"
 
 
 def check_grads(hip_g, ref_g, v, keys=util.GRAD_KEYS, rel=GRAD_REL):
@@ -73,7 +79,7 @@ def test_forward_backward_vs_c_oracle(opacity):
         np.testing.assert_array_equal(st["xy"][v][vis], os_["xy"][vis])
         np.testing.assert_array_equal(st["depth"][v][vis], os_["depth"][vis])
         np.testing.assert_array_equal(st["conic_opacity"][v][vis], os_["conic_opacity"][vis])
-        assert (st["n_contrib"][v] == os_["n_contrib"]).mean() >= 1 - FLIP_FRAC
+        check_n_contrib(st["n_contrib"][v], os_["n_contrib"])
         check_outputs(hip, r.color, r.depth, r.alpha, v)
         check_grads(hg, g, v)
 
@@ -199,7 +205,7 @@ def test_degenerate_inputs():
     for k in ("opacities", "scales", "rotations", "colors_precomp"):
         rv2[k] = rv[k].repeat(2, 1)
     hip, hg, batch = util.hip_render(cams, rv2, dc)
-    assert (hip["radii"] == 0).all() or True
+    assert (hip["radii"] == 0).all()
     for v in range(2):
         r, g = util.c_oracle_render(cams[v], rv2, dc[v])
         np.testing.assert_array_equal(hip["radii"][v], r.radii)
