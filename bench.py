@@ -2,7 +2,8 @@
 """
 bench.py — rasterizer forward+backward views/sec on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4] [--opacity A|B] [--scaling weak|strong]
+                    [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,12 +12,16 @@ One "step" = one pass of the hot path over one batch: forward + backward of the 
 all inputs already resident in HBM and seeded dL/dcolor supplied.  One "view" = one
 (Settings, params) -> colour/depth/alpha -> per-view dL/dparams round trip.
 
-Multi-GPU (BASELINE config 3): the 64-frame sequence is sharded by frame — rank r renders frames r, r+N, ...;
-per-GPU work per step is fixed (24 views) => "scaling": "weak".  The only collective is an RCCL all_gather of the
-per-view scalar losses (24 floats per rank per step).  K*N = 64 steps is the strong-scaling run of config 3.
+Multi-GPU (BASELINE config 3): the 64-frame sequence is sharded by frame — rank r renders frames r, r+N, ...
+  --scaling weak   (default; what the driver runs): every rank times K steps, per-GPU work is fixed (24 views per step);
+  --scaling strong : the job is fixed — K frame-steps in total (default 64 = config 3's sequence), K/N per rank.
+The only collective is an RCCL all_gather of the per-view scalar losses (24 floats per rank per step), overlapped with the
+next step.
 
-The JSON line carries `roofline` (dominant kernel, HIP-event duration, algorithmic bytes per launch) and
-`cpu_baseline` (oracle/raster_oracle.c, OpenMP, bounded sample) — see DESIGN.md §Measurement.
+The JSON line carries `roofline` (dominant kernel by HIP-event time, algorithmic bytes per launch, HBM traffic and the
+vector-ALU counters of the committed rocprofv3 passes), `cpu_baseline` (oracle/raster_oracle.c, OpenMP, bounded sample,
+min of 5), `scenario_b` (the same workload with unsaturated opacities) and `single_view` (the reference's own call shape:
+one camera per call, P = 8,280, 512x375) — see DESIGN.md §Measurement.
 """
 from __future__ import annotations
 
@@ -34,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 ACHIEVABLE_HBM_GBS = 6290.0
+N_SIMD = 1024                  # 256 CUs x 4 SIMD-32
 
 
 def algorithmic_bytes(P, R, HW, S=0):
@@ -51,8 +57,9 @@ def algorithmic_bytes(P, R, HW, S=0):
     return per_kernel, total
 
 
-def cpu_baseline(cfg, n_sample_views):
-    """C oracle (oracle/raster_oracle.c), OpenMP over all host cores, fwd+bwd on a bounded sample of the workload."""
+def cpu_baseline(cfg, n_sample_views, reps):
+    """C oracle (oracle/raster_oracle.c), OpenMP over all host cores, fwd+bwd on a bounded sample of the workload; min of
+    `reps` repetitions (SURVEY.md §8d asks for min-of-5)."""
     from oracle import c_oracle as CO
     from topo4d_amd import boundary, scene
     CO.build()
@@ -88,42 +95,244 @@ def cpu_baseline(cfg, n_sample_views):
                              rv.get("colors_precomp"), rv.get("shs"))
         rr.backward(dc[v])
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        list(ex.map(one, range(n_sample_views)))
-    dt = time.perf_counter() - t0
-    out = {"value": round(n_sample_views / dt, 3), "unit": "views/s", "cores": cores, "kind": "port",
+    best, spent = None, 0.0
+    done_reps = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(one, range(n_sample_views)))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        spent += dt
+        done_reps += 1
+        if spent > 25.0:                                       # bounded: the default run must finish within minutes
+            break
+    out = {"value": round(n_sample_views / best, 3), "unit": "views/s", "cores": cores, "kind": "port",
            "sample": f"{n_sample_views} of the {cfg['n_views']} views of the same scene, fwd+bwd, oracle/raster_oracle.c -O3 "
-                     f"-fopenmp, {workers} views at a time x {per} OpenMP threads, {dt:.1f}s wall"}
+                     f"-fopenmp, {workers} views at a time x {per} OpenMP threads, min of {done_reps} runs ({best:.2f}s wall each)"}
     # the same code on ONE host thread, one view (SURVEY.md 8d asks for both figures)
     try:
         gomp.omp_set_num_threads(1)
-        t1 = time.perf_counter()
-        r = CO.OracleRender(cams[0], rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
-                            rv.get("colors_precomp"), rv.get("shs"))
-        r.backward(dc[0])
-        d1 = time.perf_counter() - t1
+        d1 = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            r = CO.OracleRender(cams[0], rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                                rv.get("colors_precomp"), rv.get("shs"))
+            r.backward(dc[0])
+            dd = time.perf_counter() - t1
+            d1 = dd if d1 is None else min(d1, dd)
+            if dd > 5.0:
+                break
         gomp.omp_set_num_threads(os.cpu_count())
-        out["one_thread"] = {"value": round(1.0 / d1, 4), "unit": "views/s", "cores": 1, "sample": f"1 view, {d1:.1f}s wall"}
-    except Exception as e:                       # libgomp not loadable: report the multi-threaded figure only
+        out["one_thread"] = {"value": round(1.0 / d1, 4), "unit": "views/s", "cores": 1, "sample": f"1 view, min of up to 3 ({d1:.2f}s wall)"}
+    except Exception:                            # libgomp not loadable: report the multi-threaded figure only
         out["one_thread"] = None
     return out
+
+
+class Workload:
+    """The timed thing: `step(i)` = forward + backward of this rank's frame i (all V views in one launch set) + the per-view
+    loss scalars + (N > 1) their asynchronous all_gather."""
+
+    def __init__(self, cfgname, opacity, dev, rank=0, world=1, n_streams=1, n_frames=64, resident=8):
+        from topo4d_amd import ViewBatch, boundary, dist as t4d_dist, pack_views, scene
+        self.t4d_dist = t4d_dist
+        self.cfg = cfg = dict(scene.CONFIGS[cfgname])
+        self.dev, self.rank, self.world = dev, rank, world
+        self.H, self.W, self.V = H, W, V = cfg["H"], cfg["W"], cfg["n_views"]
+        params = scene.make_gaussians(cfg["n_lat"], cfg["n_lon"], opacity=opacity, sh_degree=cfg["sh_degree"], seed=0)
+        self.P = params["means3D"].shape[0]
+        base_means = params["means3D"].clone()
+        cams = scene.camera_rig(H, W, n_views=V, device=dev, true_campos=cfg["sh_degree"] is not None)
+        if cfg["sh_degree"] is not None:
+            cams = [c._replace(sh_degree=cfg["sh_degree"]) for c in cams]
+        views = pack_views(cams, dev)
+        dc, _, _ = scene.output_cotangents(V, H, W, seed=0)
+        dc = dc.to(dev)
+        # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
+        self.n_frames = n_frames
+        my_frames = t4d_dist.shard_units(n_frames, rank, world)
+        self.rv_frames = []
+        for t in my_frames[: max(1, min(len(my_frames), resident))]:
+            p = dict(params)
+            p["means3D"] = scene.frame_displacement(base_means, t, n_frames)
+            rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
+            if cfg["sh_degree"] is not None:
+                rv["shs"] = params["shs"].to(dev)
+                rv.pop("colors_precomp")
+            self.rv_frames.append(rv)
+        self.S = S = max(1, min(n_streams, V))
+        self.bounds = [(V * k) // S for k in range(S + 1)]
+        self.batches = [ViewBatch(views[self.bounds[k]:self.bounds[k + 1]].contiguous(), H, W, 1.0, cfg["sh_degree"] or 0)
+                        for k in range(S)]
+        self.dcs = [dc[self.bounds[k]:self.bounds[k + 1]].contiguous() for k in range(S)]
+        self.losses = torch.zeros(V, device=dev)
+        # multi-GPU: the loss all_gather of step i overlaps with step i+1 (double-buffered, waited on two steps later)
+        self.loss_bufs = [torch.zeros(V, device=dev), torch.zeros(V, device=dev)]
+        self.gath_bufs = [torch.zeros(V * world, device=dev), torch.zeros(V * world, device=dev)]
+        self.pending = [None, None]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
+
+    def step(self, i):
+        from topo4d_amd.rasterizer import view_dot
+        rv = self.rv_frames[i % len(self.rv_frames)]
+        g = []
+        S, world, dev = self.S, self.world, self.dev
+        losses = self.losses
+        if world > 1:
+            if self.pending[i % 2] is not None:
+                self.pending[i % 2].wait()
+                self.pending[i % 2] = None
+            losses = self.loss_bufs[i % 2]
+        if S > 1:
+            main = torch.cuda.current_stream(dev)
+            for st in self.streams:
+                st.wait_stream(main)
+        for k in range(S):
+            with torch.cuda.stream(self.streams[k]) if S > 1 else contextlib.nullcontext():
+                b = self.batches[k]
+                color, radii, depth, alpha = b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
+                                                       rv.get("colors_precomp"), rv.get("shs"))
+                g.append(b.backward(self.dcs[k]))
+                # per-view scalar loss term <colour, dL/dcolour>, one fused pass
+                view_dot(color, self.dcs[k], out=losses[self.bounds[k]:self.bounds[k + 1]])
+        if S > 1:
+            for st in self.streams:
+                main.wait_stream(st)
+        if world > 1:
+            out, work = self.t4d_dist.gather_losses_async(losses, self.gath_bufs[i % 2])
+            self.pending[i % 2] = work
+            return out, g
+        return losses, g
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def learn_capacity(self):
+        """first call "checked" (learns the pair-arena capacity), the rest of the run is lazy (no host sync)"""
+        import topo4d_amd
+        topo4d_amd.set_sync_mode("checked")
+        self.step(0)
+        for i in range(len(self.rv_frames)):
+            self.step(i)
+        topo4d_amd.set_sync_mode("lazy")
+
+    def statuses(self):
+        return [b.fetch_status() for b in self.batches]
+
+
+def timed_run(wl, steps, warmup, prewarm_s, barrier, all_reduce_max):
+    """W untimed steps (after a clock-settling pre-warm), then EXACTLY `steps` steps between two barriers."""
+    dev = wl.dev
+    # A GPU that has just been idle (fresh box, or a profiler run before this one) needs tens of milliseconds of work
+    # before its clocks settle: a cold 50-step run measured 1.23 ms/step against 0.62 warm.  Untimed, like the W steps.
+    torch.cuda.synchronize(dev)
+    t_pre = time.perf_counter()
+    for i in range(8):
+        wl.step(i)
+    torch.cuda.synchronize(dev)
+    est = all_reduce_max((time.perf_counter() - t_pre) / 8)          # every rank must run the same number of steps
+    n_pre = int(min(4000, max(0.0, prewarm_s) / max(est, 1e-5)))
+    for i in range(n_pre):
+        wl.step(i)
+    torch.cuda.synchronize(dev)
+    for i in range(warmup):
+        wl.step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(i)
+    t_enqueue = time.perf_counter() - t0       # host time to enqueue the steps (GPU still running)
+    barrier()
+    dt = time.perf_counter() - t0
+    return all_reduce_max(dt), t_enqueue
+
+
+def kernel_profile(wl, steps):
+    """Per-kernel durations with HIP events recorded on the launch stream inside the library (same steps again, so that the
+    timed region carries no event overhead).  Returns ({kernel: (total_ms, launches)}, wall seconds)."""
+    from topo4d_amd import _lib
+    torch.cuda.synchronize(wl.dev)
+    if wl.rank == 0:
+        _lib.profile_begin()
+    tp0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(i)
+    torch.cuda.synchronize(wl.dev)
+    tp = time.perf_counter() - tp0
+    prof = _lib.profile_end() if wl.rank == 0 else {}
+    return prof, tp
+
+
+def load_profile_json(name, config, kernel):
+    f = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f)).get(config, {}).get(kernel)
+    except Exception:
+        return None
+
+
+def single_view_probe(dev):
+    """The reference's own call shape (train.py:661-673): ONE camera per call, P = 8,280, 512x375.  GPU time per forward +
+    backward = sum of the HIP-event durations of the rasterizer's kernels; wall time per un-synchronised call pair too."""
+    import topo4d_amd
+    from topo4d_amd import ViewBatch, _lib, boundary, pack_views, scene
+    H, W = 512, 375                                                    # helpers.py:807: (3, 512, 375) images
+    p = scene.make_gaussians(69, 120, opacity="A", seed=0)             # 8,280 vertex-bound Gaussians
+    cams = scene.camera_rig(H, W, n_views=24, device=dev)
+    rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
+    g = torch.Generator().manual_seed(0)
+    dc = (torch.randn(1, 3, H, W, generator=g) / (3 * H * W)).to(dev)
+    b = ViewBatch(pack_views(cams[12:13], dev), H, W)
+    f = lambda: (b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv["colors_precomp"]), b.backward(dc))
+    topo4d_amd.set_sync_mode("checked")
+    f()
+    topo4d_amd.set_sync_mode("lazy")
+    for _ in range(100):
+        f()
+    torch.cuda.synchronize(dev)
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize(dev)
+    wall_us = 1e6 * (time.perf_counter() - t0) / n
+    _lib.profile_begin()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize(dev)
+    prof = _lib.profile_end()
+    kern = {name: round(1e3 * ms / max(cnt, 1), 2) for name, (ms, cnt) in prof.items() if cnt}
+    st = b.fetch_status()
+    return {"workload": "1 view per call, P=8280, 512x375 (HxW), opacity scenario A, forward+backward through the C ABI",
+            "gpu_us_per_view": round(sum(kern.values()), 1), "kernels_us": kern,
+            "wall_us_per_view_unsynchronised_calls": round(wall_us, 1), "views_per_s_wall": round(1e6 / wall_us, 1),
+            "pairs": int(st.total_pairs), "note": "gpu_us = sum of HIP-event kernel durations (launch gaps excluded)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; in --scaling strong: frame-steps of the whole job, default 64)")
     ap.add_argument("--prewarm-s", dest="prewarm_s", type=float, default=0.4,
                     help="seconds of untimed steps before the W warm-up steps (lets the GPU clocks ramp)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=["C2", "C4"])
     ap.add_argument("--opacity", default="A", choices=["A", "B"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the scenario-B and single-view side measurements")
     ap.add_argument("--cpu-sample-views", type=int, default=0)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("T4D_BENCH_STREAMS", "1")),
                     help="split the views of a step over this many HIP streams (independent views overlap their kernel tails)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 64 if args.scaling == "strong" else 50
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`
@@ -141,6 +350,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -149,183 +359,99 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    if args.scaling == "strong" and args.steps % world != 0:
+        raise SystemExit(f"--scaling strong: --steps {args.steps} (frame-steps of the whole job) must be a multiple of the {world} ranks")
 
     import topo4d_amd
-    from topo4d_amd import ViewBatch, _lib, boundary, dist as t4d_dist, pack_views, scene
-    from topo4d_amd.rasterizer import view_dot
 
-    cfg = dict(scene.CONFIGS[args.config])
-    H, W, V = cfg["H"], cfg["W"], cfg["n_views"]
-    params = scene.make_gaussians(cfg["n_lat"], cfg["n_lon"], opacity=args.opacity, sh_degree=cfg["sh_degree"], seed=0)
-    P = params["means3D"].shape[0]
-    base_means = params["means3D"].clone()
-    cams = scene.camera_rig(H, W, n_views=V, device=dev, true_campos=cfg["sh_degree"] is not None)
-    if cfg["sh_degree"] is not None:
-        cams = [c._replace(sh_degree=cfg["sh_degree"]) for c in cams]
-    views = pack_views(cams, dev)
-    dc, _, _ = scene.output_cotangents(V, H, W, seed=0)
-    dc = dc.to(dev)
-    dc_flat = dc.flatten(1)
-
-    # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
-    n_frames = 64
-    my_frames = t4d_dist.shard_units(n_frames, rank, world)
-    rv_frames = []
-    for t in my_frames[: max(1, min(len(my_frames), 8))]:
-        p = dict(params)
-        p["means3D"] = scene.frame_displacement(base_means, t, n_frames)
-        rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
-        if cfg["sh_degree"] is not None:
-            rv["shs"] = params["shs"].to(dev)
-            rv.pop("colors_precomp")
-        rv_frames.append(rv)
-
-    S = max(1, min(args.streams, V))
-    bounds = [(V * k) // S for k in range(S + 1)]
-    batches = [ViewBatch(views[bounds[k]:bounds[k + 1]].contiguous(), H, W, 1.0, cfg["sh_degree"] or 0) for k in range(S)]
-    dcs = [dc[bounds[k]:bounds[k + 1]].contiguous() for k in range(S)]
-    batch = batches[0]
-    losses = torch.zeros(V, device=dev)
-    # multi-GPU: the loss all_gather of step i overlaps with step i+1 (double-buffered, waited on two steps later)
-    loss_bufs = [torch.zeros(V, device=dev), torch.zeros(V, device=dev)]
-    gath_bufs = [torch.zeros(V * world, device=dev), torch.zeros(V * world, device=dev)]
-    pending = [None, None]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
-
-    def step(i):
-        nonlocal losses
-        rv = rv_frames[i % len(rv_frames)]
-        g = []
-        if world > 1:
-            if pending[i % 2] is not None:
-                pending[i % 2].wait()
-                pending[i % 2] = None
-            losses = loss_bufs[i % 2]
-        if S > 1:
-            main = torch.cuda.current_stream(dev)
-            for st in streams:
-                st.wait_stream(main)
-        for k in range(S):
-            with torch.cuda.stream(streams[k]) if S > 1 else contextlib.nullcontext():
-                color, radii, depth, alpha = batches[k].forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
-                                                                rv.get("colors_precomp"), rv.get("shs"))
-                g.append(batches[k].backward(dcs[k]))
-                # per-view scalar loss term <colour, dL/dcolour>, one fused pass
-                view_dot(color, dcs[k], out=losses[bounds[k]:bounds[k + 1]])
-        if S > 1:
-            for st in streams:
-                main.wait_stream(st)
-        if world > 1:
-            out, work = t4d_dist.gather_losses_async(losses, gath_bufs[i % 2])
-            pending[i % 2] = work
-            return out, g
-        return losses, g
-
-    def drain():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+    wl = Workload(args.config, args.opacity, dev, rank, world, args.streams)
+    cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
+    my_steps = args.steps // world if args.scaling == "strong" else args.steps
 
     def barrier():
-        drain()
+        wl.drain()
         if world > 1:
-            import torch.distributed as dist
             if dist.get_backend() == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
                 dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # warm-up: first call is "checked" (learns the pair-arena capacity), the rest of the run is lazy (no host sync)
-    topo4d_amd.set_sync_mode("checked")
-    step(0)
-    st0 = batch.fetch_status()
-    for i in range(len(rv_frames)):
-        step(i)
-    topo4d_amd.set_sync_mode("lazy")
-    # A GPU that has just been idle (fresh box, or a profiler run before this one) needs tens of milliseconds of work
-    # before its clocks settle: a cold 50-step run measured 1.23 ms/step against 0.62 warm.  Untimed, like the W steps.
-    torch.cuda.synchronize(dev)
-    t_pre = time.perf_counter()
-    for i in range(8):
-        step(i)
-    torch.cuda.synchronize(dev)
-    est = torch.tensor([(time.perf_counter() - t_pre) / 8], device=dev, dtype=torch.float64)
-    if world > 1:                                   # every rank must run the same number of steps (a step holds a collective)
-        import torch.distributed as dist
-        dist.all_reduce(est, op=dist.ReduceOp.MAX)
-    n_pre = int(min(4000, max(0.0, args.prewarm_s) / max(float(est.item()), 1e-5)))
-    for i in range(n_pre):
-        step(i)
-    torch.cuda.synchronize(dev)
-    for i in range(args.warmup):
-        step(i)
+    def all_reduce_max(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    t_enqueue = time.perf_counter() - t0       # host time to enqueue K steps (GPU still running)
-    barrier()
-    dt = time.perf_counter() - t0
-    sts = [b.fetch_status() for b in batches]
+    wl.learn_capacity()
+    dt, t_enqueue = timed_run(wl, my_steps, args.warmup, args.prewarm_s, barrier, all_reduce_max)
+    sts = wl.statuses()
     if any(x.overflow for x in sts):
         raise SystemExit("pair arena overflowed during the timed region: result invalid")
-    st = sts[0]
     total_pairs_all = sum(x.total_pairs for x in sts)
-
-    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
+    # T4D_BENCH_DUMP_LOSSES=k (tests): the gathered per-view loss vectors of this rank's first k steps go into the JSON line
+    last_losses = None
+    if os.environ.get("T4D_BENCH_DUMP_LOSSES"):
+        last_losses = []
+        for i in range(int(os.environ["T4D_BENCH_DUMP_LOSSES"])):
+            o, _ = wl.step(i)
+            wl.drain()
+            torch.cuda.synchronize(dev)
+            last_losses.append(o.detach().float().cpu().tolist())
+    barrier()
 
     # ---- per-kernel durations with HIP events (same steps again; keeps `value` free of event overhead) ----
     # Every rank replays the steps (a step contains the loss all_gather when N > 1, so all ranks must take part);
     # only rank 0 records events.
+    prof, tp = kernel_profile(wl, my_steps)
     roofline = None
-    kernels = {}
-    torch.cuda.synchronize(dev)
+    sh_bytes = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
+    R_view = total_pairs_all / V
+    per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, sh_bytes)
     if rank == 0:
-        _lib.profile_begin()
-    tp0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    tp = time.perf_counter() - tp0
-    if rank == 0:
-        prof = _lib.profile_end()
-        R_view = total_pairs_all / V
-        sh_bytes = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
-        per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, sh_bytes)
+        kernels = {}
         for name, (ms, n) in prof.items():
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": n,
                                  "alg_GBs": round(per_kernel[name] * V / (1e-3 * ms / n) / 1e9, 1)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
         ach = per_kernel[dom] * V / (kernels[dom]["avg_us"] * 1e-6) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(args.config, {}).get(dom)
-            except Exception:
-                traffic = None
+        traffic = load_profile_json("traffic.json", args.config, dom)
+        # vector-ALU counters of the committed rocprofv3 --pmc passes (tools/prof.sh -> profiles/valu.json): what actually limits
+        # the render kernels.  busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * kernel cycles).
+        valu = load_profile_json("valu.json", args.config, dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": int(per_kernel[dom] * V), "avg_us": kernels[dom]["avg_us"],
-                    "pairs_per_view": int(R_view), "ms_per_step_profiled": round(1e3 * tp / args.steps, 4),
-                    "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels}
-
+                    "pairs_per_view": int(R_view), "ms_per_step_profiled": round(1e3 * tp / my_steps, 4),
+                    "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels,
+                    "valu": valu,
+                    "measured_limiter": ("vector-ALU issue" if valu and valu.get("valu_busy", 0) > 0.6 else None)}
     if world > 1:
         barrier()
 
+    # ---- side measurements on one GPU: scenario B (unsaturated opacities) and the reference's one-view-per-call shape ----
+    scenario_b = single_view = None
+    if world == 1 and not args.no_extras:
+        try:
+            if args.opacity == "A":
+                wb = Workload(args.config, "B", dev)
+                wb.learn_capacity()
+                dtb, _ = timed_run(wb, my_steps, args.warmup, 0.1, lambda: torch.cuda.synchronize(dev), lambda x: x)
+                stb = wb.statuses()
+                scenario_b = {"value": round(V * my_steps / dtb, 2), "unit": "views/s", "ms_per_step": round(1e3 * dtb / my_steps, 4),
+                              "steps": my_steps, "pairs_per_view": int(sum(x.total_pairs for x in stb) / V),
+                              "overflow": bool(any(x.overflow for x in stb)),
+                              "workload": "same as config.workload with opacity scenario B: uniform(0.05, 0.95)"}
+                del wb
+            single_view = single_view_probe(dev)
+        except Exception as e:          # side measurements must never take the headline number down with them
+            scenario_b = scenario_b or {"error": str(e)}
+        topo4d_amd.set_sync_mode("lazy")
+
     if rank == 0:
-        views_total = V * args.steps * world
+        views_total = V * my_steps * world
         value = views_total / dt
-        _, total_bytes = algorithmic_bytes(P, total_pairs_all / V, H * W,
-                                           0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4)
         if roofline is not None:
             roofline["pipeline_frac_of_peak"] = round(value / world * total_bytes / 1e9 / PEAK_HBM_GBS, 4)
             roofline["pipeline_frac_of_achievable"] = round(value / world * total_bytes / 1e9 / ACHIEVABLE_HBM_GBS, 4)
@@ -333,25 +459,27 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             n_s = args.cpu_sample_views or (24 if args.config == "C2" else 4)
             try:
-                cpu = cpu_baseline(cfg, n_s)
+                cpu = cpu_baseline(cfg, n_s, reps=5)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cpu = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         out = {
             "metric": "rasterizer fwd+bwd views/sec", "value": round(value, 2), "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / my_steps, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {V} views x {H}x{W}, P={P} vertex-bound Gaussians, "
                                    f"{'SH degree %d' % cfg['sh_degree'] if cfg['sh_degree'] is not None else 'precomputed RGB'}, "
                                    f"opacity scenario {args.opacity}, forward+backward, per-view gradients",
-                       "views_per_step_per_gpu": V, "frames": n_frames, "parallelism": f"frame-sharded x{world}",
+                       "views_per_step_per_gpu": V, "frames": wl.n_frames, "steps_per_rank": my_steps,
+                       "parallelism": f"frame-sharded x{world}",
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
-                       "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4), "hip_streams": S},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "hip_streams": wl.S},
+            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view,
         }
+        if last_losses is not None:
+            out["gathered_losses_first_steps"] = last_losses
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

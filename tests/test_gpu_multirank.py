@@ -1,0 +1,52 @@
+"""GPU: the N > 1 control flow of bench.py executed for real before an 8-GPU node ever sees it — two ranks sharing the one
+GPU of the test box (T4D_BENCH_SHARE_GPU=1), gloo instead of RCCL for the loss gather (T4D_DIST_BACKEND=gloo), launched the
+way the driver launches it (python -m torch.distributed.run ... bench.py --gpus 2 ...)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _run(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling,steps", [("weak", 3), ("strong", 6)])
+def test_two_rank_dry_run_matches_single_rank_frame_by_frame(scaling, steps):
+    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras"]
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", str(steps), "--scaling", scaling] + common,
+               dict(env, T4D_BENCH_DUMP_LOSSES="2"))
+    one = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", str(steps), "--scaling", scaling] + common,
+               dict(env, T4D_BENCH_DUMP_LOSSES="4"))
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == scaling
+    assert two["config"]["parallelism"] == "frame-sharded x2"
+    assert two["config"]["steps_per_rank"] == (steps // 2 if scaling == "strong" else steps)
+    assert two["value"] > 0 and two["roofline"]["kernel"] in ("k_render_bwd", "k_render_fwd")
+    # rank r renders frames r, r+2, ...: the vector gathered at local step i holds [frame 2i (rank 0), frame 2i+1 (rank 1)],
+    # 24 per-view losses each; the single rank renders frames 0, 1, 2, 3 at its steps 0..3.  Kernels are deterministic:
+    # the numbers must agree bit for bit.
+    g2 = np.asarray(two["gathered_losses_first_steps"], np.float32)        # [2 steps, 48]
+    g1 = np.asarray(one["gathered_losses_first_steps"], np.float32)        # [4 steps, 24]
+    assert g2.shape == (2, 48) and g1.shape == (4, 24)
+    for i in range(2):
+        np.testing.assert_array_equal(g2[i, :24], g1[2 * i])
+        np.testing.assert_array_equal(g2[i, 24:], g1[2 * i + 1])
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0

@@ -34,22 +34,53 @@ def check_outputs(hip, ref_color, ref_depth, ref_alpha, v, max_flips=0):
         assert err.max() <= FLIP_MAX, f"{name}[view {v}]: max err {err.max():.3e}"
 
 
-def check_n_contrib(mine, ref, max_flips=0):
-    diff = int((np.asarray(mine) != np.asarray(ref)).sum())
-    assert diff <= max_flips, f"n_contrib differs on {diff} pixels"
+def flipped_pixels(hip, v, r, n_contrib_mine):
+    """(y, x) of the pixels where a discrete decision fell the other way than in the C oracle `r`."""
+    bad = n_contrib_mine != r.state()["n_contrib"]
+    for name, ref in (("color", r.color), ("depth", r.depth), ("alpha", r.alpha)):
+        a = hip[name][v]
+        bad |= (np.abs(a.astype(np.float64) - np.asarray(ref, np.float64).reshape(a.shape)) > OUT_TOL).any(axis=0)
+    return np.argwhere(bad)
 
 
-def check_grads(hip_g, ref_g, v, keys=util.GRAD_KEYS, rel=GRAD_REL):
+def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_KEYS, rel=GRAD_REL):
+    """check_grads for images of millions of pixels, where a handful of threshold decisions (`flips`, from flipped_pixels)
+    differ from the oracle: a Gaussian may exceed the relative tolerance ONLY IF a flipped pixel lies inside its 3-sigma
+    square (its gradient then differs by that pixel's contribution); the absolute bound GRAD_ABS holds for all."""
     for k in keys:
         if k not in ref_g or ref_g[k] is None or hip_g.get(k) is None:
             continue
         a = hip_g[k][v].astype(np.float64)
         b = np.asarray(ref_g[k], np.float64).reshape(a.shape)
         scale = max(np.abs(b).max(), 1e-30)
-        err = np.abs(a - b).max()
+        err = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
+        assert err.max() < GRAD_ABS, f"grad {k}[view {v}]: abs err {err.max():.3e}"
+        for i in np.nonzero(err > rel * scale + 1e-9)[0]:
+            near = (np.abs(flips[:, 1] - xy[i, 0]) <= radii[i] + 1) & (np.abs(flips[:, 0] - xy[i, 1]) <= radii[i] + 1) \
+                if len(flips) else np.zeros(0, bool)
+            assert near.any(), f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} with no flipped pixel in reach"
+
+
+def check_n_contrib(mine, ref, max_flips=0):
+    diff = int((np.asarray(mine) != np.asarray(ref)).sum())
+    assert diff <= max_flips, f"n_contrib differs on {diff} pixels"
+
+
+def check_grads(hip_g, ref_g, v, keys=util.GRAD_KEYS, rel=GRAD_REL, max_bad_rows=0):
+    """max-abs-err <= rel * max|reference| per tensor.  `max_bad_rows` (0 unless an adversarial test says otherwise) Gaussians
+    may exceed that - a pixel whose alpha >= 1/255 decision flipped moves one splat's gradient by a whole contribution -
+    but never the absolute bound GRAD_ABS."""
+    for k in keys:
+        if k not in ref_g or ref_g[k] is None or hip_g.get(k) is None:
+            continue
+        a = hip_g[k][v].astype(np.float64)
+        b = np.asarray(ref_g[k], np.float64).reshape(a.shape)
+        scale = max(np.abs(b).max(), 1e-30)
+        err = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
         # 1e-9 floor: a gradient that cancels to exactly 0 in one summation order is ~1e-11 in another
-        assert err <= rel * scale + 1e-9, f"grad {k}[view {v}]: max-abs-err {err:.3e} vs scale {scale:.3e}"
-        assert err < GRAD_ABS, f"grad {k}[view {v}]: abs err {err:.3e}"
+        bad = int((err > rel * scale + 1e-9).sum())
+        assert bad <= max_bad_rows, f"grad {k}[view {v}]: {bad} Gaussians off, max-abs-err {err.max():.3e} vs scale {scale:.3e}"
+        assert err.max() < GRAD_ABS, f"grad {k}[view {v}]: abs err {err.max():.3e}"
 
 
 @pytest.mark.parametrize("opacity", ["A", "B"])

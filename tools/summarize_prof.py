@@ -66,3 +66,25 @@ with open(os.path.join(out, "pmc_summary.txt"), "w") as o:
         for c, v in sorted(summary[k].items()):
             o.write(f"    {c:28s} {v['avg_per_launch']:18.1f}  (n={v['launches']})\n")
 print(open(os.path.join(out, "pmc_summary.txt")).read())
+
+# compact per-kernel counters for bench.py: HBM-side traffic (bytes per launch) and the vector-ALU picture
+# (tools/merge_counters.py copies them into profiles/traffic.json and profiles/valu.json under a config name)
+def _avg(k, c):
+    v = summary.get(k, {}).get(c)
+    return None if v is None else v["avg_per_launch"]
+counters = {"traffic": {}, "valu": {}}
+for k in summary:
+    if not k.startswith("k_"):
+        continue
+    f, w = _avg(k, "FETCH_SIZE"), _avg(k, "WRITE_SIZE")
+    if f is not None and w is not None:
+        counters["traffic"][k] = int((2 * f + w) * 1024)        # FETCH_SIZE doubled: MI355X_MICROARCH.md, HBM section
+    insts, act, gui = _avg(k, "SQ_INSTS_VALU"), _avg(k, "SQ_ACTIVE_INST_VALU"), _avg(k, "GRBM_GUI_ACTIVE")
+    if insts is not None and act is not None and gui:
+        cycles = gui / 8.0                                      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        counters["valu"][k] = {"SQ_INSTS_VALU": int(insts), "SQ_ACTIVE_INST_VALU_quad_cycles": int(act),
+                               "kernel_cycles": int(cycles), "valu_busy": round(act * 4.0 / (1024 * cycles), 4),
+                               "valu_cycles_per_inst": round(act * 4.0 / insts, 2),
+                               "SQ_INSTS_SALU": int(_avg(k, "SQ_INSTS_SALU") or 0), "SQ_INSTS_LDS": int(_avg(k, "SQ_INSTS_LDS") or 0),
+                               "SQ_WAVES": int(_avg(k, "SQ_WAVES") or 0)}
+json.dump(counters, open(os.path.join(out, "counters.json"), "w"), indent=1)

@@ -11,7 +11,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libtopo4d_raster.so")
+# T4D_LIB: load another build of the SAME library (an experiment build next to the shipped one, tools/ab_build.sh); there
+# is still no fallback - a path that does not load raises.
+LIB_PATH = os.environ.get("T4D_LIB") or os.path.join(HERE, "csrc", "libtopo4d_raster.so")
 
 T4D_ABI_VERSION = 1
 T4D_VIEW_FLOATS = 40

@@ -157,7 +157,11 @@ struct KP {
 // ---------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * S - 1.0f) * 0.5f; }
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{
+#pragma clang fp contract(off)      // (v + 1) * S - 1 must not become an fma: S is not a power of two for 512x375 / 4096x3008 images
+    return ((v + 1.0f) * S - 1.0f) * 0.5f;
+}
 
 __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
 {
