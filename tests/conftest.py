@@ -24,3 +24,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["throughput", "latency"])
+def render_build(request, monkeypatch):
+    """Runs a test once with each build of the per-tile render kernels (csrc/t4d_raster.hip: LAT = false / true), whatever
+    the launch size would have picked."""
+    monkeypatch.setenv("T4D_LATENCY_TILES", "0" if request.param == "throughput" else "1000000000")
+    return request.param

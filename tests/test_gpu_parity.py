@@ -84,7 +84,7 @@ def check_grads(hip_g, ref_g, v, keys=util.GRAD_KEYS, rel=GRAD_REL, max_bad_rows
 
 
 @pytest.mark.parametrize("opacity", ["A", "B"])
-def test_forward_backward_vs_c_oracle(opacity):
+def test_forward_backward_vs_c_oracle(opacity, render_build):
     H = W = 128
     V = 4
     rv, cams = util.make_scene(30, 50, H, W, V, opacity=opacity, seed=1)
@@ -116,7 +116,7 @@ def test_forward_backward_vs_c_oracle(opacity):
 
 
 @pytest.mark.parametrize("opacity", ["A", "B"])
-def test_gradients_vs_autograd_f64(opacity):
+def test_gradients_vs_autograd_f64(opacity, render_build):
     """Ground truth: torch.autograd over the float64 restatement (oracle/torch_oracle.py)."""
     H = W = 96
     V = 2
@@ -173,7 +173,7 @@ def test_cov3d_precomp_path():
                 keys=("means3D", "means2D", "opacities", "colors_precomp", "cov3D_precomp"))
 
 
-def test_ragged_image_and_background():
+def test_ragged_image_and_background(render_build):
     """512x375-style image (not a multiple of 16, helpers.py:807) and a non-zero background."""
     H, W, V = 75, 100, 3
     rv, cams = util.make_scene(16, 24, H, W, V, opacity="B", seed=11, bg=[0.2, 0.5, 0.9])
@@ -186,7 +186,7 @@ def test_ragged_image_and_background():
         check_grads(hg, g, v)
 
 
-def test_long_tile_lists_and_global_sort_path():
+def test_long_tile_lists_and_global_sort_path(render_build):
     """Thousands of large Gaussians on 4x4 tiles: every bin is longer than one LDS batch (256) and longer than
     the LDS sort buffer (4096), so the multi-batch blend/replay and the global-memory sort path both run."""
     H = W = 64
@@ -244,7 +244,7 @@ def test_degenerate_inputs():
         check_grads(hg, g, v)
 
 
-def test_bitwise_determinism():
+def test_bitwise_determinism(render_build):
     H = W = 128
     V = 3
     rv, cams = util.make_scene(30, 50, H, W, V, opacity="B", seed=21)
@@ -259,7 +259,7 @@ def test_bitwise_determinism():
             np.testing.assert_array_equal(ga[k], gb[k])
 
 
-def test_views_batched_equals_views_one_by_one():
+def test_views_batched_equals_views_one_by_one(render_build):
     H = W = 96
     V = 5
     rv, cams = util.make_scene(20, 32, H, W, V, opacity="B", seed=31)
@@ -273,6 +273,30 @@ def test_views_batched_equals_views_one_by_one():
         for k in ga:
             if ga[k] is not None:
                 np.testing.assert_array_equal(ga[k][v], gb[k][0])
+
+
+def test_latency_and_throughput_builds_agree(monkeypatch):
+    """The two builds of the render kernels share every per-pixel operation: forward outputs and state are bit-equal; the
+    backward adds the same partial sums in a different fixed order (one slab per DPP row instead of one per wave)."""
+    H, W, V = 100, 75, 3
+    rv, cams = util.make_scene(24, 40, H, W, V, opacity="B", seed=41)
+    from topo4d_amd import scene
+    dc, dd, da = scene.output_cotangents(V, H, W, seed=42, depth_alpha=True)
+    res = {}
+    for name, lim in (("throughput", "0"), ("latency", "1000000000")):
+        monkeypatch.setenv("T4D_LATENCY_TILES", lim)
+        out, g, batch = util.hip_render(cams, rv, dc, dd, da)
+        st = util.decode_state(batch)
+        res[name] = (out, g, st)
+    a, b = res["throughput"], res["latency"]
+    for k in a[0]:
+        np.testing.assert_array_equal(a[0][k], b[0][k])
+    np.testing.assert_array_equal(a[2]["n_contrib"], b[2]["n_contrib"])
+    np.testing.assert_array_equal(a[2]["final_T"], b[2]["final_T"])
+    for k in a[1]:
+        if a[1][k] is not None:
+            scale = np.abs(a[1][k]).max()
+            assert np.abs(a[1][k].astype(np.float64) - b[1][k]).max() <= 2e-6 * scale + 1e-12, k
 
 
 def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():

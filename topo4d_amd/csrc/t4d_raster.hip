@@ -924,24 +924,35 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
     return cnt;
 }
 
-// pad a row's list with the null entry up to (and three entries beyond) the wave's longest list: every row then walks
-// the same number of steps without a per-step bounds test
+// pad a row's list with the null entry up to (and GROUP - 1 entries beyond) the wave's longest list: every row then walks
+// the same number of steps, GROUP at a time, without a per-step bounds test
+template <int GROUP = 4>
 __device__ __forceinline__ void pad_visit_list(unsigned short *list, const int cnt, const int nsteps, const int lane,
                                                const unsigned short null_entry)
 {
 #pragma clang loop vectorize(disable) unroll(disable)
-    for (int p2 = cnt + lane; p2 < nsteps + 3; p2 += 64) list[p2] = null_entry;
+    for (int p2 = cnt + lane; p2 < nsteps + GROUP - 1; p2 += 64) list[p2] = null_entry;
 }
 
 #ifndef T4D_FWD_WAVES
 #define T4D_FWD_WAVES 6          // 80 VGPRs, no spills; 7 waves (72 VGPRs) spill inside the batch loop and measure 5 % slower
 #endif
-#define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(T4D_FWD_WAVES, T4D_FWD_WAVES)))
+// Two instantiations of each per-tile render kernel.  LAT = false is the THROUGHPUT build (many tiles in flight, bound by
+// vector-ALU issue: registers are capped for occupancy, steps go four at a time).  LAT = true is the LATENCY build, chosen by
+// the host when a launch holds too few tiles to fill the chip (the reference's own call shape: ONE view of 768 tiles per
+// call, train.py:661-673): every CU then runs one workgroup whose duration is the dependent-instruction chain of its
+// longest visit list, so this build spends registers and LDS freely on instruction-level parallelism - eight steps per
+// group with all their LDS reads issued up front, no exec-mask branches between the steps, one backward slab per DPP row
+// (no same-splat conflicts to serialise).  Per-pixel arithmetic and its order are IDENTICAL in both builds: forward
+// outputs are bit-equal; the backward's partial sums are added up in a different (still fixed) order.
+#define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_FWD_WAVES, LAT ? 2 : T4D_FWD_WAVES)))
+template <bool LAT>
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
+    constexpr int kU = LAT ? 8 : 4;                  // steps per group
     constexpr int kNull = kFwdBatch;                 // staged slot that can never contribute (opacity 0)
     constexpr int kChunks = kFwdBatch / 64;
-    constexpr int kListStride = kFwdBatch + 4;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
+    constexpr int kListStride = kFwdBatch + 8;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
     constexpr int kRec = 48;                         // bytes per staged splat: xy (8, +8 pad) | scaled conic + opacity | rgb + depth
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFwdBatch + 1) * kRec];
     __shared__ unsigned long long s_mask[16][kChunks];
@@ -1005,21 +1016,27 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             nsteps = max(nsteps, cnts[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) pad_visit_list(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kRec));
+        for (int r = 0; r < 4; r++) pad_visit_list<kU>(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kRec));
         __builtin_amdgcn_wave_barrier();
         const unsigned short *list = s_list[wave][row];
 #if T4D_ABL == 5
         nsteps = 0;
 #endif
         uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
-        for (int k = 0; k < nsteps; k += 4) {
-            const uint2 pk = *reinterpret_cast<const uint2 *>(list + k);
-            const uint32_t e[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
-            float alpha[4];
-            bool valid[4];
+        for (int k = 0; k < nsteps; k += kU) {
+            uint32_t e[kU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {                // four independent evaluations: ILP hides LDS / exp latency
+            for (int h = 0; h < kU / 4; h++) {
+                const uint2 pk = *reinterpret_cast<const uint2 *>(list + k + 4 * h);
+                e[4 * h] = pk.x & 0xffffu; e[4 * h + 1] = pk.x >> 16; e[4 * h + 2] = pk.y & 0xffffu; e[4 * h + 3] = pk.y >> 16;
+            }
+            float alpha[kU];
+            bool valid[kU];
+            float4 cds[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {               // independent evaluations: ILP hides LDS / exp latency
                 const v2f g_xy = *reinterpret_cast<const v2f *>(s_rec + e[u]);
+                if (LAT) cds[u] = *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);      // every LDS read of the group up front
                 float p2, G;
                 eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy - pix_f, p2, G, alpha[u]);
                 valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
@@ -1030,13 +1047,13 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 #endif
             // (no "does any lane blend?" test: with four different splats in flight per step the answer is almost always yes)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {                // blending is sequential in list order
+            for (int u = 0; u < kU; u++) {               // blending is sequential in list order
                 bool ok = valid[u] && !done;
                 const float test_T = T * (1.f - alpha[u]);
                 const bool below = test_T < T4D_T_STOP;
                 done = done || (ok && below);
                 ok = ok && !below;
-                const float4 cd = *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);
+                const float4 cd = LAT ? cds[u] : *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);
                 const float w = ok ? alpha[u] * T : 0.f;
                 C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
                 D = fmaf(cd.w, w, D);
@@ -1153,11 +1170,22 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #ifndef T4D_BWD_WAVES
 #define T4D_BWD_WAVES 5
 #endif
-#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(T4D_BWD_WAVES, T4D_BWD_WAVES)))
+#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_BWD_WAVES, LAT ? 2 : T4D_BWD_WAVES)))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
-template <bool DA>
+#ifdef T4D_TIMING      // experiment builds only (tools/ab_build.sh timing -DT4D_TIMING): s_memtime stamps of workgroup 0's phases
+__device__ unsigned long long g_timing[512];
+#define T4D_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 512) g_timing[(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define T4D_STAMP(i) do { } while (0)
+#endif
+// LAT: the latency build (see k_render_fwd): one slab per DPP ROW instead of one per wave (82 KB of LDS: one workgroup per CU
+// is all such a launch has anyway), so two rows holding the same splat in the same step never meet and the conflict
+// detection and its branches disappear; the gradient arithmetic is predicated with selects instead of an exec-masked region,
+// which lets the compiler interleave the four steps of a group.
+template <bool DA, bool LAT>
 __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
+    constexpr int kSlabs = LAT ? 16 : 4;
     constexpr int kChunks = kBwdBatch / 64;
     constexpr int kListStride = kBwdBatch + 4;
     constexpr int kEnt = 8;                  // list entries are slot * 8: byte offset into s_xy, half the offset into s_q / s_cd
@@ -1167,7 +1195,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
     __shared__ float4 s_cd[kBwdBatch + 1];
     __shared__ uint32_t s_pair[kBwdBatch];
-    __shared__ __attribute__((aligned(8))) float s_acc[4][kBwdBatch + 1][kAcc];   // + the null splat's (never read) row
+    __shared__ __attribute__((aligned(8))) float s_acc[kSlabs][kBwdBatch + 1][kAcc];   // + the null splat's (never read) row
     __shared__ unsigned long long s_mask[16][kChunks];
     __shared__ uint32_t s_wmax[4];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
@@ -1184,12 +1212,16 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_cd[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = tid; i < 4 * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
+    for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
     for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {
     const uint4 it = kp.items[item];
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
+    T4D_STAMP(0);
+#ifdef T4D_TIMING
+    if (blockIdx.x == 0 && tid == 0) g_timing[5] = wall_clock64();
+#endif
     if (n == 0) break;                                             // ordered by length: only empty tiles remain
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
@@ -1234,8 +1266,13 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
     const int nb = (int)((n + kBwdBatch - 1) / kBwdBatch);
+    T4D_STAMP(1);
+#ifdef T4D_TIMING
+    if (blockIdx.x == 0 && tid == 0) { g_timing[2] = n; g_timing[3] = tile_max; }
+#endif
     for (int bi = nb - 1; bi >= 0; bi--) {
         const uint32_t lo = (uint32_t)bi * kBwdBatch;
+        T4D_STAMP(8 + 8 * (nb - 1 - bi));
         const int cnt = (int)min((uint32_t)kBwdBatch, n - lo);
         const bool live = lo < tile_max;      // workgroup-uniform
         // ---- stage ----
@@ -1266,6 +1303,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             }
         }
         __syncthreads();
+        T4D_STAMP(9 + 8 * (nb - 1 - bi));
         if (live) {
             int nsteps = 0, cnts[4];
 #pragma unroll
@@ -1291,7 +1329,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #pragma unroll
             for (int c2 = 0; c2 < kChunks; c2++) {
                 conflict[c2] = 0ull;
-                if ((c2 << 6) < nsteps) {
+                if (!LAT && (c2 << 6) < nsteps) {
                     const int st = (c2 << 6) + lane;
                     const unsigned short *l0 = s_list[wave][0];
                     const uint32_t e0 = l0[st], e1 = l0[kListStride + st], e2 = l0[2 * kListStride + st], e3 = l0[3 * kListStride + st];
@@ -1308,7 +1346,11 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             const unsigned char *xy_b = reinterpret_cast<const unsigned char *>(s_xy);
             const unsigned char *q_b = reinterpret_cast<const unsigned char *>(s_q);
             const unsigned char *cd_b = reinterpret_cast<const unsigned char *>(s_cd);
-            unsigned char *slab = reinterpret_cast<unsigned char *>(&s_acc[wave][0][0] + (my_slot >= 0 ? my_slot : 0));
+            // LAT: lanes that keep no sum write (zeros plus whatever) into distinct floats of the null splat's row of their slab
+            unsigned char *slab = LAT ? reinterpret_cast<unsigned char *>(my_slot >= 0 ? &s_acc[wave * 4 + row][0][my_slot]
+                                                                                      : &s_acc[wave * 4 + row][kNull][(lane & 15) % kAcc])
+                                      : reinterpret_cast<unsigned char *>(&s_acc[wave][0][0] + (my_slot >= 0 ? my_slot : 0));
+            const uint32_t slab_mul = (!LAT || my_slot >= 0) ? (uint32_t)(kAcc * 4 / kEnt) : 0u;
             // entry of the first staged splat this pixel did NOT see in the forward pass (entries are slot * kEnt)
             const int lc_rel = (int)min(last_contributor - min(last_contributor, lo), (uint32_t)kBwdBatch) * kEnt;
 #if T4D_ABL == 3
@@ -1319,6 +1361,10 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             // geometry records, and a step's slab value is read BEFORE its arithmetic and written back after it
             // (same wave, program order: the previous step's write is already ahead of the read in the LDS queue).
             uint2 pk = *reinterpret_cast<const uint2 *>(list);
+            T4D_STAMP(10 + 8 * (nb - 1 - bi));
+#ifdef T4D_TIMING
+            if (blockIdx.x == 0 && tid == 0) g_timing[13 + 8 * (nb - 1 - bi)] = nsteps;
+#endif
             for (int k = 0; k < nsteps; k += 4) {
                 const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
                 pk = *reinterpret_cast<const uint2 *>(list + k + 4);          // the lists are padded: always readable
@@ -1340,14 +1386,30 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     const bool contrib = contribs[u];
                     const v2f d = ds[u];
                     const float G = Gs[u], alpha = alphas[u];
-                    float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], kAcc * 4 / kEnt));
+                    float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], slab_mul));
                     const float old = *dst;              // early read of the slab value this step adds to
                     float e = 0.f, w = 0.f;
 #if T4D_ABL == 2
                     if (contrib) e = alpha + G + d.x + d.y;
                     if (false) {
 #else
-                    if (contrib) {
+                    if (LAT) {
+                        // the same operations in the same order as the exec-masked region below, on every lane; the selects keep
+                        // the state of the lanes that do not contribute
+                        const float4 cd = cds[u];
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        const float Tn = T * inv;
+                        float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
+                        if (DA) q = fmaf(cd.w, ddep, q) + dalp;
+                        const float accn = fmaf(last_alpha, last_q, (1.f - last_alpha) * acc);
+                        const float dL_dalpha = fmaf(q - accn, Tn, -tf_bg * inv);
+                        T = contrib ? Tn : T;
+                        w = contrib ? alpha * Tn : 0.f;
+                        acc = contrib ? accn : acc;
+                        last_q = contrib ? q : last_q;
+                        last_alpha = contrib ? alpha : last_alpha;
+                        e = contrib ? G * dL_dalpha : 0.f;
+                    } else if (contrib) {
 #endif
                         // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
                         // the splat centre, and w * dL/dC.  Everything that is constant per splat (opacity, conic,
@@ -1375,7 +1437,9 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Idle
                     // rows add their zeros to the null splat's row, which nobody reads.
                     const bool add = my_slot >= 0;
-                    if (!((cbits >> u) & 1u)) {
+                    if (LAT) {
+                        *dst = old + tot;                // own slab per row: never a conflict; slot-less lanes hit their dummy float
+                    } else if (!((cbits >> u) & 1u)) {
                         if (add) *dst = old + tot;
                     } else {
 #pragma unroll
@@ -1389,14 +1453,16 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                 }
             }
         }
+        T4D_STAMP(11 + 8 * (nb - 1 - bi));
         __syncthreads();
+        T4D_STAMP(12 + 8 * (nb - 1 - bi));
         // ---- write one record per pair (zeros when no wave touched it); fixed wave order => deterministic ----
         if (tid < cnt) {
             float a[10];
 #pragma unroll
             for (int k = 0; k < 10; k++) a[k] = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < kSlabs; w++) {
                 float2 *src = reinterpret_cast<float2 *>(&s_acc[w][tid][0]);
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
@@ -1413,6 +1479,10 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         }
         __syncthreads();
     }
+    T4D_STAMP(4);
+#ifdef T4D_TIMING
+    if (blockIdx.x == 0 && tid == 0) g_timing[6] = wall_clock64();
+#endif
     }
 }
 
@@ -1756,6 +1826,14 @@ int tile_grid(int n_tiles, int per_cu, int div)
     return max(min(n_tiles, device_cus() * per_cu), (n_tiles + div - 1) / div);
 }
 
+// A launch of at most this many tiles runs the LATENCY builds of the render kernels: with <= 4 workgroups per CU in total
+// nothing queues behind anything, and a kernel lasts as long as its longest tile (T4D_LATENCY_TILES overrides; 0 = never).
+bool latency_launch(int n_tiles)
+{
+    const char *e = getenv("T4D_LATENCY_TILES");        // read per call: the tests switch builds at run time
+    return n_tiles <= (e ? atoi(e) : 4 * device_cus());
+}
+
 int check_problem(const T4DProblem *p)
 {
     if (!p) return fail(T4D_ERR_ARG, "null problem");
@@ -1908,7 +1986,10 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     }
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
-    hipLaunchKernelGGL(k_render_fwd, dim3(tile_grid(kp.T * p.n_views, 6, 2)), dim3(kBlock), 0, stream, kp);
+    if (latency_launch(kp.T * p.n_views))
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+    else
+        hipLaunchKernelGGL(k_render_fwd<false>, dim3(tile_grid(kp.T * p.n_views, 6, 2)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
     return T4D_OK;
@@ -1952,10 +2033,14 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
 
     { ProfScope ps_(stream, K_RENDER_BWD);
-    if (kp.dL_ddepth || kp.dL_dalpha)
-        hipLaunchKernelGGL(k_render_bwd<true>, dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
-    else
-        hipLaunchKernelGGL(k_render_bwd<false>, dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
+    const bool da = kp.dL_ddepth || kp.dL_dalpha;
+    if (latency_launch(kp.T * p.n_views)) {
+        if (da) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_bwd<false, true>), dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+    } else {
+        if (da) hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_bwd<false, false>), dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
+    }
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
@@ -1964,6 +2049,13 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;
 }
+
+#ifdef T4D_TIMING
+T4D_EXPORT int t4d_debug_read_timing(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timing), sizeof(unsigned long long) * (size_t)min(n, 512));
+}
+#endif
 
 T4D_EXPORT int t4d_profile_begin(void)
 {
