@@ -59,9 +59,12 @@ enum {
                                   instead of rendering truncated tile lists (what upstream's num_rendered D2H does) */
     T4D_FLAG_DEBUG_SYNC = 2u,  /* `debug=True` of the settings tuple: synchronise + check after every kernel */
     T4D_FLAG_PREFILTERED = 4u, /* accepted for API parity (helpers.py:84 passes False); no effect */
-    T4D_FLAG_ASYNC_STATUS = 8u /* forward, without CHECKED: `status` must point at PINNED host memory; the first 16 bytes
+    T4D_FLAG_ASYNC_STATUS = 8u,/* forward, without CHECKED: `status` must point at PINNED host memory; the first 16 bytes
                                   receive { uint32 overflow; uint32 max_pairs_per_view; uint64 total_pairs } by an
                                   asynchronous copy enqueued behind the binning kernels — no host synchronisation */
+    T4D_FLAG_NO_LONG_BINS = 16u/* forward: the caller knows (T4DStatus.max_tile_pairs of an earlier call on this scene) that no
+                                  tile list exceeds 2048 pairs: the launch of the long-bin sort kernel is skipped.  Only a
+                                  speed hint — longer bins that show up anyway are still sorted correctly, just slowly */
 };
 
 typedef struct T4DProblem {
@@ -81,7 +84,7 @@ typedef struct T4DStatus {
     int64_t max_pairs_per_view;  /* largest per-view number of (Gaussian,tile) pairs this call needed */
     int64_t total_pairs;         /* sum over views (upstream's num_rendered, summed) */
     int32_t overflow;            /* 1 if any view exceeded pair_capacity (its tile lists were truncated) */
-    int32_t reserved;
+    int32_t max_tile_pairs;      /* longest per-tile list of the call (dense passes reach > 10^4; see T4D_FLAG_NO_LONG_BINS) */
 } T4DStatus;
 
 typedef struct T4DForwardIO {
@@ -157,6 +160,15 @@ size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int32_t W);
 int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *cam_m,
                          const float *cam_c, const float *view_weight, float *loss, float *dL_dim, float *dL_dcam_m,
                          float *dL_dcam_c, void *scratch, size_t scratch_bytes, void *hip_stream);
+
+/* Masked L1 of the dense (texture) pass, train.py:394-405 (get_loss_dense with use_mask=True): no camera affine, no SSIM,
+ *     loss[v] = sum over { mask == 1 } of |im - gt|  /  count{ mask == 1 },     dL_dim = view_weight[v] * sign(im - gt) / count there, 0 elsewhere.
+ * im, gt, mask, dL_dim: [V,3,H,W]; mask is the float image of zeros and ones helpers.get_mask (helpers.py:811-823) returns
+ * (the three channels carry the same plane; they are all counted, like `masked_index.sum()`).  An empty mask gives NaN, as
+ * in the reference. */
+size_t t4d_masked_l1_scratch_bytes(int32_t n_views);
+int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *mask,
+                       const float *view_weight, float *loss, float *dL_dim, void *scratch, size_t scratch_bytes, void *hip_stream);
 
 /* Fused optimiser step of Topo4D's loop: torch.optim.Adam (one group per tensor, train.py:272-297) for up to
  * T4D_ADAM_MAX_TENSORS tensors in ONE launch, followed by the per-iteration region freezes of train.py:676-700

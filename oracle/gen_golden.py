@@ -12,6 +12,8 @@ G3  helpers.l1_loss_v1 + external.calc_ssim (helpers.py:115-116, external.py:73-
     with the gradient of 0.8*L1 + 0.2*(1-SSIM) w.r.t. the rendered image (train.py:315)
 G4  helpers.eval_sh               (helpers.py:865-922) degrees 0..3 on seeded [P=32,3,16] coefficients
 G7  helpers.compute_vertex_attribute_by_weight_2 (helpers.py:237-253) on a seeded quad mesh
+G8  train.get_loss_dense(..., use_mask=True) (train.py:380-417: helpers.get_mask + the masked L1 of :394-405), called for
+    real with `Renderer` bound to a stub that returns a seeded render: loss['im'] and its gradient w.r.t. the render
 G6  SELF-GENERATED (not reference-derived): forward outputs + all gradients of oracle/torch_oracle.py (float64)
     on a 64x64 / P=200 scene; pins the oracle against accidental edits.
 The rasterizer itself has no reference-derived golden vectors: its source is absent from /root/reference
@@ -74,6 +76,57 @@ def import_reference_helpers():
     import external  # noqa
     import helpers  # noqa
     return helpers, external
+
+
+def import_reference_train():
+    """train.py itself (after import_reference_helpers): modules it needs beyond the stubs above are stubbed on demand."""
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return lambda *a, **kw: None
+    for _ in range(40):
+        try:
+            import train  # noqa
+            return train
+        except ModuleNotFoundError as e:
+            sys.modules[e.name] = _Any(e.name)
+    raise RuntimeError("could not import the reference train.py")
+
+
+def gen_g8(helpers):
+    train = import_reference_train()
+    H, W, P = 48, 40, 8
+    g = torch.Generator().manual_seed(8)
+    cmap = np.asarray(helpers.cmap)                                        # helpers.py:806 (uint8 [14,3], BGR order)
+    target_colors = [torch.tile(torch.tensor(cmap[i]).reshape(3, 1, 1), (1, H, W)) for i in range(14)]     # as helpers.py:807
+    labels = torch.randint(0, 14, (H // 4, W // 4), generator=g).repeat_interleave(4, 0).repeat_interleave(4, 1)
+    mask = torch.stack([torch.tensor(cmap[:, c].astype(np.float32))[labels] for c in range(3)]) / 255.0   # the [3,H,W] label image
+    im = torch.rand(3, H, W, generator=g).requires_grad_(True)
+    gt = torch.rand(3, H, W, generator=g)
+    radius = torch.zeros(P, dtype=torch.int32)
+
+    class StubRenderer:                                                    # stands in for the un-vendored rasterizer only
+        def __init__(self, raster_settings=None):
+            pass
+
+        def __call__(self, **kw):
+            return im, radius, None, None
+    train.Renderer = StubRenderer
+    params = {"dense_means3D": torch.rand(P, 3, generator=g), "dense_rgb_colors": torch.rand(P, 3, generator=g),
+              "dense_unnorm_rotations": torch.rand(P, 4, generator=g), "dense_logit_opacities": torch.zeros(P, 1),
+              "dense_log_scales": torch.zeros(P, 3)}
+    variables = {"target_colors_dense": target_colors, "dense_init_colors": torch.rand(P, 3, generator=g),
+                 "dense_max_2D_radius": torch.zeros(P)}
+    curr = {"cam": None, "im": gt, "mask": mask, "id": 0}
+    loss, variables, detail = train.get_loss_dense(params, curr, variables, 0, 0, None, use_mask=True, losses_list={},
+                                                   losses_weights={"im": 1.0, "soft_color": 0.0})
+    loss.backward()
+    target_labels = ["skin", "l_eyebrow", "r_eyebrow", "nose", "upper_lip", "lower_lip", "l_ear", "r_ear", "hair"]   # train.py:396-398
+    filtered = helpers.get_mask(target_labels, mask, train.cmap_index, target_colors)
+    np.savez_compressed(os.path.join(OUT, "g8_masked_l1.npz"), im=im.detach().numpy(), gt=gt.numpy(), mask_image=mask.numpy(),
+                        filtered_mask=filtered.numpy(), loss_im=np.float32(detail["im"].item()), grad_im=im.grad.numpy(),
+                        masked_elements=np.int64((filtered == 1).sum().item()))
 
 
 def main():
@@ -159,6 +212,9 @@ def main():
     dense = helpers.compute_vertex_attribute_by_weight_2(variables, attr)
     np.savez(os.path.join(OUT, "g7_dense_interp.npz"), quads=quads, father=father, weight=wgt, attr=attr, dense=dense,
              dense_f32=torch.tensor(dense).float().numpy())
+
+    # ---- G8 -------------------------------------------------------------------------------------------------
+    gen_g8(helpers)
 
     # ---- G6 (self-generated) --------------------------------------------------------------------------------
     from oracle import torch_oracle as TO

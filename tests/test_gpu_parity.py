@@ -186,24 +186,33 @@ def test_ragged_image_and_background(render_build):
         check_grads(hg, g, v)
 
 
-def test_long_tile_lists_and_global_sort_path(render_build):
-    """Thousands of large Gaussians on 4x4 tiles: every bin is longer than one LDS batch (256) and longer than
-    the LDS sort buffer (4096), so the multi-batch blend/replay and the global-memory sort path both run."""
+@pytest.mark.parametrize("P,hint", [(5000, "unknown"), (5000, "no-long-bins"), (20000, "unknown")])
+def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch):
+    """Thousands of large Gaussians on 4x4 tiles: every bin is longer than one LDS batch (256) and longer than k_sort_tiles'
+    LDS buffer (2048), so the multi-batch blend/replay and the long-bin sort run: k_sort_long in LDS (5,000 keys per bin), its
+    chunk + global-merge path (20,000 keys per bin > 16,384), and - when the host wrongly hinted "no long bins" - the slow
+    in-kernel fallback of k_sort_tiles."""
+    from topo4d_amd import rasterizer
     H = W = 64
     V = 1
-    P = 5000
     g = torch.Generator().manual_seed(3)
     rv = dict(means3D=(torch.rand(P, 3, generator=g) - 0.5) * torch.tensor([0.2, 0.2, 0.1]),
-              opacities=torch.rand(P, 1, generator=g) * 0.05 + 0.01,
+              opacities=torch.rand(P, 1, generator=g) * (0.05 if P <= 5000 else 0.01) + 0.01,
               scales=torch.rand(P, 3, generator=g) * 0.05 + 0.08,
               rotations=torch.nn.functional.normalize(torch.randn(P, 4, generator=g)),
               colors_precomp=torch.rand(P, 3, generator=g))
     from topo4d_amd import scene
     cams = scene.camera_rig(H, W, n_views=1)
     dc, dd, da = scene.output_cotangents(V, H, W, seed=4, depth_alpha=True)
+    rasterizer._LONGEST_BIN.clear()
+    if hint == "no-long-bins":
+        monkeypatch.setitem(rasterizer._LONGEST_BIN, (0, P, H, W), 100)
+        monkeypatch.setitem(rasterizer._CAPACITY, (0, P, H, W), 16 * P + 1024)     # known scene size: no checked retry
     hip, hg, batch = util.hip_render(cams, rv, dc, dd, da)
+    if hint == "no-long-bins":
+        assert batch.prob.flags & 16
     st = util.decode_state(batch)
-    assert st["tile_count"].max() > 4096
+    assert st["tile_count"].max() > (16384 if P > 5000 else 4096)
     r, gref = util.c_oracle_render(cams[0], rv, dc[0], dd[0], da[0])
     os_ = r.state()
     counts = os_["ranges"][:, 1] - os_["ranges"][:, 0]
@@ -212,8 +221,12 @@ def test_long_tile_lists_and_global_sort_path(render_build):
         off = int(st["tile_off"][0, t])
         mine = (st["keys"][0, off: off + counts[t]] & np.uint64(0xffffffff)).astype(np.uint32)
         np.testing.assert_array_equal(mine, os_["point_list"][os_["ranges"][t, 0]: os_["ranges"][t, 1]])
-    check_outputs(hip, r.color, r.depth, r.alpha, 0)
-    check_grads(hg, gref, 0, rel=5e-4)
+    assert batch.fetch_status().max_tile_pairs == counts.max()
+    # every pixel blends thousands of splats whose opacity (0.01 .. 0.06) is a few times the 1/255 threshold: each splat has a
+    # ring of pixels where alpha crosses it, so a few of the ~10^8 decisions may fall the other way than with glibc's expf
+    check_outputs(hip, r.color, r.depth, r.alpha, 0, max_flips=3)
+    check_grads(hg, gref, 0, rel=5e-4, max_bad_rows=3)
+    rasterizer._LONGEST_BIN.clear()
 
 
 def test_degenerate_inputs():

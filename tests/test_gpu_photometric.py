@@ -80,3 +80,33 @@ def test_feeds_the_rasterizer_backward():
     for k in res[0][1]:
         a, b = res[0][1][k], res[1][1][k]
         assert (a - b).abs().max() <= 1e-4 * b.abs().max() + 1e-10, k
+
+
+def test_masked_l1_matches_reference_golden_g8_and_torch():
+    """t4d_masked_l1_loss: the dense pass's masked L1 (train.py:394-405).  G8 holds the numbers the real get_loss_dense returned."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_masked_l1.npz"))
+    im = torch.tensor(g["im"])[None].cuda().requires_grad_(True)
+    l = loss.masked_l1_loss(im, torch.tensor(g["gt"])[None].cuda(), torch.tensor(g["filtered_mask"])[None].cuda())
+    l.sum().backward()
+    assert abs(l[0].item() - float(g["loss_im"])) < 2e-7
+    np.testing.assert_allclose(im.grad[0].cpu().numpy(), g["grad_im"], rtol=1e-6, atol=0)
+    # a batch of full-resolution dense-pass views against the torch restatement, with per-view weights
+    V, H, W = 3, 1504, 2048
+    gen = torch.Generator().manual_seed(3)
+    imb = torch.rand(V, 3, H, W, generator=gen)
+    gtb = torch.rand(V, 3, H, W, generator=gen)
+    plane = (torch.rand(V, 1, H // 8, W // 8, generator=gen) > 0.4).float().repeat_interleave(8, 2).repeat_interleave(8, 3)
+    mask = plane.expand(V, 3, H, W).contiguous()
+    mask[2] = 0                                                   # an empty mask: NaN loss, zero gradient, like the reference
+    wv = torch.tensor([1.0, 0.5, 2.0])
+    a = imb.cuda().requires_grad_(True)
+    lb = loss.masked_l1_loss(a, gtb.cuda(), mask.cuda())
+    (lb[:2] * wv[:2].cuda()).sum().backward()
+    for v in range(2):
+        ref_in = imb[v].double().requires_grad_(True)
+        ref = loss.masked_l1_loss_torch(ref_in, gtb[v].double(), mask[v].double())
+        (ref * wv[v].double()).backward()
+        assert abs(lb[v].item() - ref.item()) < 2e-6 * ref.item()
+        np.testing.assert_allclose(a.grad[v].cpu().numpy(), ref_in.grad.numpy(), rtol=1e-5, atol=1e-12)
+    assert torch.isnan(lb[2]) and not a.grad[2].any()
+    assert torch.equal(loss.masked_l1_loss(a, gtb.cuda(), mask.cuda())[:2], lb[:2])            # deterministic

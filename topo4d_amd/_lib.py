@@ -20,7 +20,7 @@ T4D_VIEW_FLOATS = 40
 T4D_GRAD_PAIR_FLOATS = 10
 
 T4D_OK, T4D_ERR_ARG, T4D_ERR_HIP, T4D_ERR_PAIR_OVERFLOW, T4D_ERR_STATE_SIZE = 0, 1, 2, 3, 4
-T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_PREFILTERED, T4D_FLAG_ASYNC_STATUS = 1, 2, 4, 8
+T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_PREFILTERED, T4D_FLAG_ASYNC_STATUS, T4D_FLAG_NO_LONG_BINS = 1, 2, 4, 8, 16
 
 # every symbol include/topo4d_raster.h declares (tests/test_abi.py checks header <-> this list <-> the .so)
 EXPORTS = (
@@ -28,6 +28,7 @@ EXPORTS = (
     "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
     "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end", "t4d_view_dot", "t4d_view_dot_scratch_bytes",
     "t4d_texture_bake", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
+    "t4d_masked_l1_loss", "t4d_masked_l1_scratch_bytes",
     "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
 )
 
@@ -41,7 +42,7 @@ class T4DProblem(C.Structure):
 
 class T4DStatus(C.Structure):
     _fields_ = [("max_pairs_per_view", C.c_int64), ("total_pairs", C.c_int64), ("overflow", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("max_tile_pairs", C.c_int32)]
 
 
 class T4DForwardIO(C.Structure):
@@ -123,6 +124,10 @@ def load():
     lib.t4d_photometric_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.t4d_photometric_loss.restype = C.c_int
     lib.t4d_photometric_loss.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p]
+    lib.t4d_masked_l1_scratch_bytes.restype = C.c_size_t
+    lib.t4d_masked_l1_scratch_bytes.argtypes = [C.c_int32]
+    lib.t4d_masked_l1_loss.restype = C.c_int
+    lib.t4d_masked_l1_loss.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
     lib.t4d_adam_pin_step.restype = C.c_int
     lib.t4d_adam_pin_step.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.t4d_adam_pin_step_graph.restype = C.c_int

@@ -262,7 +262,98 @@ __global__ __launch_bounds__(kBlock) void k_photo_final(const PhP P)
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// ---------------------------------------------------------------------------------------------------------
+// Masked L1 of the dense (texture) pass, reference train.py:394-405 (get_loss_dense, use_mask=True):
+//     masked_index = filtered_mask == 1;   loss = sum_{masked} |im - gt| / masked_index.sum()
+// (no camera affine, no SSIM; filtered_mask = helpers.get_mask(...), a float [3,H,W] image of zeros and ones).
+// Two launches per batch of views: partial sums + counts, then a fixed-order total per view and the gradient
+// dL/dim = weight * sign(im - gt) / count on the masked elements, 0 elsewhere.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMlBlocks = 128;            // partial sums per view
+
+__global__ __launch_bounds__(kBlock) void k_masked_l1_partial(const float *im, const float *gt, const float *mask, size_t n,
+                                                              float *part_sum, uint32_t *part_cnt)
+{
+    __shared__ float s_red[4];
+    __shared__ uint32_t s_cnt[4];
+    const int v = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)v * n;
+    float acc = 0.f;
+    uint32_t cnt = 0;
+    for (size_t i = (size_t)blk * kBlock + tid; i < n; i += (size_t)kMlBlocks * kBlock) {
+        if (mask[base + i] == 1.0f) { acc += fabsf(im[base + i] - gt[base + i]); cnt++; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); cnt += (uint32_t)__shfl_xor((int)cnt, d, 64); }
+    if ((tid & 63) == 0) { s_red[tid >> 6] = acc; s_cnt[tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        part_sum[(size_t)v * kMlBlocks + blk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        part_cnt[(size_t)v * kMlBlocks + blk] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_masked_l1_grad(const float *im, const float *gt, const float *mask, size_t n,
+                                                           const float *part_sum, const uint32_t *part_cnt, const float *weight,
+                                                           float *loss, float *dL_dim)
+{
+    __shared__ float s_tot;
+    __shared__ float s_count;
+    const int v = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {                                                   // fixed-order total of the view's partials
+        float a = part_sum[(size_t)v * kMlBlocks + tid] + part_sum[(size_t)v * kMlBlocks + 64 + tid];
+        unsigned long long c = (unsigned long long)part_cnt[(size_t)v * kMlBlocks + tid] + part_cnt[(size_t)v * kMlBlocks + 64 + tid];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            a += __shfl_xor(a, d, 64);
+            c += ((unsigned long long)(uint32_t)__shfl_xor((int)(c >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)c, d, 64);
+        }
+        if (tid == 0) { s_tot = a; s_count = (float)c; }
+    }
+    __syncthreads();
+    const float count = s_count;
+    if (blk == 0 && tid == 0) loss[v] = s_tot / count;                // 0 / 0 = NaN, like the reference's empty mask
+    const float g = (weight ? weight[v] : 1.f) / count;
+    const size_t base = (size_t)v * n;
+    for (size_t i = (size_t)blk * kBlock + tid; i < n; i += (size_t)gridDim.x * kBlock) {
+        float o = 0.f;
+        if (mask[base + i] == 1.0f) {
+            const float d = im[base + i] - gt[base + i];
+            o = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+        }
+        dL_dim[base + i] = o;
+    }
+}
+
 }  // namespace
+
+T4D_EXPORT size_t t4d_masked_l1_scratch_bytes(int32_t n_views)
+{
+    return n_views < 1 ? 0 : 2 * align_up((size_t)n_views * kMlBlocks * 4);
+}
+
+T4D_EXPORT int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *mask,
+                                  const float *view_weight, float *loss, float *dL_dim, void *scratch, size_t scratch_bytes,
+                                  void *hip_stream)
+{
+    static_assert(kMlBlocks == 128, "k_masked_l1_grad sums two partials per lane of one wave");
+    if (n_views < 1 || H < 1 || W < 1 || !im || !gt || !mask || !loss || !dL_dim || !scratch)
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_masked_l1_loss: bad arguments%s", "");
+    if (n_views > 65535) return t4d_internal_fail(T4D_ERR_ARG, "t4d_masked_l1_loss: too many views%s", "");
+    if (scratch_bytes < t4d_masked_l1_scratch_bytes(n_views))
+        return t4d_internal_fail(T4D_ERR_STATE_SIZE, "t4d_masked_l1_loss: scratch too small%s", "");
+    const size_t n = (size_t)3 * H * W;
+    float *part_sum = (float *)scratch;
+    uint32_t *part_cnt = (uint32_t *)((char *)scratch + align_up((size_t)n_views * kMlBlocks * 4));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(k_masked_l1_partial, dim3(kMlBlocks, n_views), dim3(kBlock), 0, stream, im, gt, mask, n, part_sum, part_cnt);
+    const unsigned gblocks = (unsigned)((n + (size_t)kBlock * 8 - 1) / ((size_t)kBlock * 8));
+    hipLaunchKernelGGL(k_masked_l1_grad, dim3(gblocks < 1 ? 1 : gblocks, n_views), dim3(kBlock), 0, stream, im, gt, mask, n,
+                       (const float *)part_sum, (const uint32_t *)part_cnt, view_weight, loss, dL_dim);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_masked_l1_loss launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}
 
 T4D_EXPORT size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int32_t W)
 {

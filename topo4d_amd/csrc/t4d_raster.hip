@@ -59,7 +59,10 @@ constexpr int kFwdBatch = T4D_FWD_BATCH;   // splats staged in LDS per round of 
 #define T4D_BWD_BATCH 128
 #endif
 constexpr int kBwdBatch = T4D_BWD_BATCH;   // splats staged per round of the backward replay (64 or 128)
-constexpr int kSortLdsCap = 2048;    // keys sorted in LDS (16 KiB: 8 workgroups per CU); longer bins use the global-memory path
+constexpr int kSortLdsCap = 2048;    // keys sorted in LDS by k_sort_tiles (16 KiB: 8 workgroups per CU); longer bins go to k_sort_long
+constexpr int kLongBlock = 1024;     // k_sort_long: threads per workgroup ...
+constexpr int kLongCap = 16384;      // ... and keys it sorts in LDS (128 KiB: one workgroup per CU)
+constexpr int kScanChunk = 1024;     // tiles scanned per workgroup of k_scan_tiles
 constexpr int kRankSortMax = 512;    // bins up to this length: register-sorted runs of 64 + one ranking pass (one barrier)
 constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
 constexpr int kBuckets = 24;         // tile-length classes (floor(log2 n), descending; last = empty) for launch ordering
@@ -81,13 +84,14 @@ std::vector<ProfRec> g_prof;
 // ---------------------------------------------------------------------------------------------------------
 struct Layout {
     size_t status, view_total, view_cursor, tile_count, bucket_fill, zero_end;
-    size_t tile_off, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, sort_tmp, final_T, n_contrib, total;
+    size_t tile_off, chunk_sum, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, sort_tmp, final_T, n_contrib, total;
 };
 
 struct DevStatus {            // first bytes of the state buffer
     uint32_t overflow;
     uint32_t max_pairs;
-    unsigned long long total_pairs;
+    unsigned long long total_pairs;       // ... the 16 bytes T4D_FLAG_ASYNC_STATUS copies out end here
+    uint32_t max_tile_pairs;              // longest tile list of the call (reported as T4DStatus.max_tile_pairs)
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -107,6 +111,7 @@ Layout make_layout(const T4DProblem &p)
     L.bucket_fill = o;   o = align_up(o + kBuckets * 4);
     L.zero_end = o;
     L.tile_off = o;      o = align_up(o + V * T * 4);
+    L.chunk_sum = o;     o = align_up(o + V * ((T + kScanChunk - 1) / kScanChunk) * 4);
     L.order = o;         o = align_up(o + (size_t)kBuckets * V * T * 4);
     L.items = o;         o = align_up(o + V * T * 16);
     L.xy = o;            o = align_up(o + V * P * 8);
@@ -135,7 +140,9 @@ struct KP {
     const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
     // state
     DevStatus *status;
-    uint32_t *view_total, *view_cursor, *tile_count, *bucket_fill, *tile_off, *order, *pair_off, *pair_rank;
+    uint32_t *view_total, *view_cursor, *tile_count, *bucket_fill, *tile_off, *chunk_sum, *order, *pair_off, *pair_rank;
+    int n_chunks;                    // scan chunks per view = ceil(T / kScanChunk)
+    int long_bins_elsewhere;         // 1: k_sort_long runs behind k_sort_tiles and takes the bins longer than kSortLdsCap
     uint4 *items;
     float2 *xy;
     float *depth;
@@ -543,46 +550,74 @@ __device__ __forceinline__ uint32_t tile_order_id(const KP &kp, const TileOrder 
     return kp.order[(size_t)k * kp.V * kp.T + (b - base)];           // (view << 20) | tile
 }
 
-__global__ __launch_bounds__(1024) void k_scan_tiles(const KP kp)
+// Dense passes have tens of thousands of tiles per view (48,128 at 4096x3008): the scan is cut into chunks of kScanChunk tiles,
+// one workgroup each.  k_tile_chunk_sums (launched only when there is more than one chunk) adds up every chunk; a chunk's
+// workgroup of k_scan_tiles then starts from the sum of the chunks before it.
+__global__ __launch_bounds__(kScanChunk) void k_tile_chunk_sums(const KP kp)
 {
-    __shared__ uint32_t s_wave_tot[16];
+    __shared__ uint32_t s_w[kScanChunk / 64];
+    const int v = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, t = c * kScanChunk + tid;
+    uint32_t x = t < kp.T ? kp.tile_count[(size_t)v * kp.T + t] : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d, 64);
+    if ((tid & 63) == 0) s_w[tid >> 6] = x;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kScanChunk / 64; w++) tot += s_w[w];
+        kp.chunk_sum[(size_t)v * kp.n_chunks + c] = tot;
+    }
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_scan_tiles(const KP kp)
+{
+    __shared__ uint32_t s_wave_tot[16], s_wave_max[16];
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_bcnt[kBuckets], s_bbase[kBuckets];
-    const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int v = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
     uint32_t *off = kp.tile_off + (size_t)v * kp.T;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < kp.T; base += 1024) {
-        const int t = base + tid;
-        const uint32_t c = t < kp.T ? cnt[t] : 0u;
-        const uint32_t incl = wave_incl_scan(c);
-        if (lane == 63) s_wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
+    if (chunk == 0) {
+        if (tid == 0) s_carry = 0;
+    } else if (wave == 0) {                                 // pairs in the chunks before this one (64 chunks per round)
+        uint32_t part = 0;
+        for (int i = lane; i < chunk; i += 64) part += kp.chunk_sum[(size_t)v * kp.n_chunks + i];
 #pragma unroll
-        for (int w = 0; w < 16; w++) {
-            const uint32_t x = s_wave_tot[w];
-            if (w < wave) woff += x;
-            tot += x;
-        }
-        const uint32_t carry = s_carry;
-        if (t < kp.T) off[t] = carry + woff + incl - c;
-        if (tid < kBuckets) s_bcnt[tid] = 0;
-        __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
-        // launch order: bucket the tiles of this chunk by list length
-        const int bk = count_bucket(c);
-        uint32_t r = 0;
-        if (t < kp.T) r = atomicAdd(&s_bcnt[bk], 1u);
-        __syncthreads();
-        if (tid < kBuckets) s_bbase[tid] = s_bcnt[tid] ? atomicAdd(&kp.bucket_fill[tid], s_bcnt[tid]) : 0u;
-        __syncthreads();
-        if (t < kp.T) kp.order[(size_t)bk * kp.V * kp.T + s_bbase[bk] + r] = ((uint32_t)v << 20) | (uint32_t)t;
-        __syncthreads();
+        for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+        if (lane == 0) s_carry = part;
     }
-    if (tid == 0) {
-        const uint32_t total = s_carry;
+    if (tid < kBuckets) s_bcnt[tid] = 0;
+    __syncthreads();
+    const int t = chunk * kScanChunk + tid;
+    const uint32_t c = t < kp.T ? cnt[t] : 0u;
+    const uint32_t incl = wave_incl_scan(c);
+    uint32_t longest = c;                                   // longest list of the chunk -> status (policy input of the host)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
+    if (lane == 63) { s_wave_tot[wave] = incl; s_wave_max[wave] = longest; }
+    // launch order: bucket the tiles of this chunk by list length
+    const int bk = count_bucket(c);
+    uint32_t r = 0;
+    if (t < kp.T) r = atomicAdd(&s_bcnt[bk], 1u);
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    longest = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t x = s_wave_tot[w];
+        if (w < wave) woff += x;
+        tot += x;
+        longest = max(longest, s_wave_max[w]);
+    }
+    const uint32_t carry = s_carry;
+    if (t < kp.T) off[t] = carry + woff + incl - c;
+    if (tid < kBuckets) s_bbase[tid] = s_bcnt[tid] ? atomicAdd(&kp.bucket_fill[tid], s_bcnt[tid]) : 0u;
+    if (tid == 0 && longest > 0) atomicMax(&kp.status->max_tile_pairs, longest);
+    __syncthreads();
+    if (t < kp.T) kp.order[(size_t)bk * kp.V * kp.T + s_bbase[bk] + r] = ((uint32_t)v << 20) | (uint32_t)t;
+    if (tid == 0 && chunk == kp.n_chunks - 1) {
+        const uint32_t total = carry + tot;
         kp.view_total[v] = total;
         uint32_t fill = 0;                                  // fullest pair-slot segment of this view
         for (uint32_t k = 0; k < kp.nseg; k++) fill = max(fill, kp.view_cursor[v * kCursorSegs + k]);
@@ -684,16 +719,27 @@ __device__ __forceinline__ uint32_t run_lower_bound(const unsigned long long *ru
     return pos + (run[pos] < key ? 1u : 0u);
 }
 
+// number of keys smaller than `key` among run[0..len) (sorted, global memory)
+__device__ __forceinline__ uint32_t lower_bound_global(const unsigned long long *run, const uint32_t len, const uint32_t cap2,
+                                                       const unsigned long long key)
+{
+    uint32_t pos = 0;
+    for (uint32_t st = cap2 >> 1; st > 0; st >>= 1)                  // cap2 = power of two >= len
+        if (pos + st <= len && run[pos + st - 1] < key) pos += st;
+    return pos + ((pos < len && run[pos] < key) ? 1u : 0u);
+}
+
 // Sort n <= kSortLdsCap keys (global memory, in place) through the workgroup's LDS buffer: runs of 64 are sorted in
 // registers, then at every level each key finds its slot in the merged pair of runs as (position in its own run) + (keys of
 // the sibling run below it), log2(width)+1 dependent LDS reads; keys wait in registers between the read and the write phase.
 // log2(n/64) levels with two barriers each (a compare-exchange network needs ~60 barriers at this size).
+template <int BLOCK, int CAP>
 __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const uint32_t n, unsigned long long *s_keys,
                                                const int tid, const int wave, const int lane)
 {
-    constexpr int kPer = kSortLdsCap / kBlock;
+    constexpr int kPer = CAP / BLOCK;
     const uint32_t runs = (n + 63u) >> 6, N = runs << 6;
-    for (uint32_t r = (uint32_t)wave; r < runs; r += 4) {
+    for (uint32_t r = (uint32_t)wave; r < runs; r += BLOCK / 64) {
         const uint32_t i = (r << 6) + (uint32_t)lane;
         unsigned long long k0 = i < n ? keys[i] : ~0ull;           // the last run is padded with +inf
         wave_sort64(k0, lane);
@@ -705,7 +751,7 @@ __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const u
         uint32_t np[kPer];
 #pragma unroll
         for (int e = 0; e < kPer; e++) {
-            const uint32_t p = (uint32_t)tid + e * kBlock;
+            const uint32_t p = (uint32_t)tid + e * BLOCK;
             if (p < N) {
                 kk[e] = s_keys[p];
                 const uint32_t run = p / w, sbase = (run ^ 1u) * w;
@@ -721,21 +767,47 @@ __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const u
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < kPer; e++)
-            if ((uint32_t)tid + e * kBlock < N) s_keys[np[e]] = kk[e];
+            if ((uint32_t)tid + e * BLOCK < N) s_keys[np[e]] = kk[e];
         __syncthreads();
     }
-    for (uint32_t i = tid; i < n; i += kBlock) keys[i] = s_keys[i];
+    for (uint32_t i = tid; i < n; i += BLOCK) keys[i] = s_keys[i];
     __syncthreads();
 }
 
-// number of keys smaller than `key` among run[0..len) (sorted, global memory)
-__device__ __forceinline__ uint32_t lower_bound_global(const unsigned long long *run, const uint32_t len, const uint32_t cap2,
-                                                       const unsigned long long key)
+// Sort a bin longer than the LDS buffer: chunks of CAP keys are sorted through the LDS, then merged level by level IN GLOBAL
+// MEMORY by the same ranking step, ping-pong between the key arena and the scratch arena of the same size (the bin's keys
+// stay in this XCD's L2).  Four independent binary searches per thread and step overlap their latencies.
+template <int BLOCK, int CAP>
+__device__ __forceinline__ void sort_bin_chunked(unsigned long long *keys, unsigned long long *tmp, const uint32_t n,
+                                                 unsigned long long *s_keys, const int tid, const int wave, const int lane)
 {
-    uint32_t pos = 0;
-    for (uint32_t st = cap2 >> 1; st > 0; st >>= 1)                  // cap2 = power of two >= len
-        if (pos + st <= len && run[pos + st - 1] < key) pos += st;
-    return pos + ((pos < len && run[pos] < key) ? 1u : 0u);
+    for (uint32_t c = 0; c < n; c += CAP) sort_chunk_lds<BLOCK, CAP>(keys + c, min((uint32_t)CAP, n - c), s_keys, tid, wave, lane);
+    unsigned long long *src = keys, *dst = tmp;
+    for (uint32_t w = CAP; w < n; w <<= 1) {
+        __threadfence_block();
+        __syncthreads();                                   // the previous level's writes are visible to the workgroup
+        for (uint32_t i0 = (uint32_t)tid * 4u; i0 < n; i0 += BLOCK * 4u) {
+            unsigned long long kk[4];
+            uint32_t slot[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) kk[e] = i0 + e < n ? src[i0 + e] : ~0ull;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t i = i0 + e, run = i / w, sbase = (run ^ 1u) * w;
+                const uint32_t slen = sbase < n ? min(w, n - sbase) : 0u;
+                slot[e] = (run & ~1u) * w + (i & (w - 1u)) + lower_bound_global(src + sbase, slen, w, kk[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (i0 + e < n) dst[slot[e]] = kk[e];
+        }
+        unsigned long long *t2 = src; src = dst; dst = t2;
+    }
+    if (src != keys) {
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += BLOCK) keys[i] = src[i];
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
@@ -778,41 +850,34 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
                 }
             }
         } else if (n <= (uint32_t)kSortLdsCap) {
-            sort_chunk_lds(keys, n, s_keys, tid, wave, lane);
-        } else {
-            // A bin longer than the LDS buffer (dense passes: ~100 of 22,000 bins at P = 1M, 4096x3008): chunks of kSortLdsCap
-            // keys are sorted through the LDS, then merged level by level IN GLOBAL MEMORY by the same ranking step, ping-pong
-            // between the key arena and the scratch arena of the same size (the bin's keys stay in this XCD's L2).  Four
-            // independent binary searches per thread and step overlap their latencies.
-            for (uint32_t c = 0; c < n; c += kSortLdsCap) sort_chunk_lds(keys + c, min((uint32_t)kSortLdsCap, n - c), s_keys, tid, wave, lane);
-            unsigned long long *src = keys, *dst = kp.sort_tmp + (size_t)v * kp.cap + off;
-            for (uint32_t w = kSortLdsCap; w < n; w <<= 1) {
-                __threadfence_block();
-                __syncthreads();                                   // the previous level's writes are visible to the workgroup
-                for (uint32_t i0 = (uint32_t)tid * 4u; i0 < n; i0 += kBlock * 4u) {
-                    unsigned long long kk[4];
-                    uint32_t slot[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) kk[e] = i0 + e < n ? src[i0 + e] : ~0ull;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const uint32_t i = i0 + e, run = i / w, sbase = (run ^ 1u) * w;
-                        const uint32_t slen = sbase < n ? min(w, n - sbase) : 0u;
-                        slot[e] = (run & ~1u) * w + (i & (w - 1u)) + lower_bound_global(src + sbase, slen, w, kk[e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (i0 + e < n) dst[slot[e]] = kk[e];
-                }
-                unsigned long long *t2 = src; src = dst; dst = t2;
-            }
-            if (src != keys) {
-                __threadfence_block();
-                __syncthreads();
-                for (uint32_t i = tid; i < n; i += kBlock) keys[i] = src[i];
-            }
+            sort_chunk_lds<kBlock, kSortLdsCap>(keys, n, s_keys, tid, wave, lane);
+        } else if (!kp.long_bins_elsewhere) {
+            // only when the host said that no such bin exists (T4D_FLAG_NO_LONG_BINS) and one appeared nevertheless:
+            // correct, but one 256-thread workgroup per bin - k_sort_long is the fast path
+            sort_bin_chunked<kBlock, kSortLdsCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
         }
         __syncthreads();                                           // s_keys is reused by the next item
+    }
+}
+
+// Bins longer than kSortLdsCap keys (dense passes: 191 of 11,544 non-empty bins at P = 1M, 4096x3008, the longest 15,693 keys)
+// get a whole CU each: 1024 threads and 128 KiB of LDS sort up to kLongCap keys without touching memory in between (runs of
+// 64 in registers, then log2(n/64) ranking merges in LDS); even longer bins fall back to LDS-sorted chunks merged in global
+// memory.  Work items are ordered by length, so the long bins are items 0, 1, ... and a workgroup stops at the first short one.
+__global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
+{
+    __shared__ unsigned long long s_keys[kLongCap];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_items = (uint32_t)(kp.V * kp.T);
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint4 it = kp.items[item];
+        const int v = (int)(it.x >> 20);
+        const uint32_t off = it.y, n = it.z;
+        if (n <= (uint32_t)kSortLdsCap) break;
+        unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+        if (n <= (uint32_t)kLongCap) sort_chunk_lds<kLongBlock, kLongCap>(keys, n, s_keys, tid, wave, lane);
+        else sort_bin_chunked<kLongBlock, kLongCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
+        __syncthreads();
     }
 }
 
@@ -1875,6 +1940,9 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.items = reinterpret_cast<uint4 *>(st + L.items);
     kp.pair_rank = reinterpret_cast<uint32_t *>(st + L.pair_rank);
     kp.tile_off = reinterpret_cast<uint32_t *>(st + L.tile_off);
+    kp.chunk_sum = reinterpret_cast<uint32_t *>(st + L.chunk_sum);
+    kp.n_chunks = (kp.T + kScanChunk - 1) / kScanChunk;
+    kp.long_bins_elsewhere = (p.flags & T4D_FLAG_NO_LONG_BINS) ? 0 : 1;
     kp.pair_off = reinterpret_cast<uint32_t *>(st + L.pair_off);
     kp.xy = reinterpret_cast<float2 *>(st + L.xy);
     kp.depth = reinterpret_cast<float *>(st + L.depth);
@@ -1958,7 +2026,8 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     }
     T4D_LAUNCH_CHECK("k_preprocess");
     { ProfScope ps_(stream, K_SCAN_TILES);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(p.n_views), dim3(1024), 0, stream, kp);
+    if (kp.n_chunks > 1) hipLaunchKernelGGL(k_tile_chunk_sums, dim3(kp.n_chunks, p.n_views), dim3(kScanChunk), 0, stream, kp);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(kp.n_chunks, p.n_views), dim3(kScanChunk), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_scan_tiles");
     if (checked) {
@@ -1969,7 +2038,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
             status->max_pairs_per_view = hs.max_pairs;
             status->total_pairs = (int64_t)hs.total_pairs;
             status->overflow = (int32_t)hs.overflow;
-            status->reserved = 0;
+            status->max_tile_pairs = (int32_t)min(hs.max_tile_pairs, 0x7fffffffu);
         }
         if (hs.overflow) return fail(T4D_ERR_PAIR_OVERFLOW, "pair_capacity too small for this scene");
     } else if ((p.flags & T4D_FLAG_ASYNC_STATUS) && status) {
@@ -1984,6 +2053,8 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     { ProfScope ps_(stream, K_SORT_TILES);
     hipLaunchKernelGGL(k_sort_tiles, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
     }
+    if (kp.long_bins_elsewhere)
+        hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
     if (latency_launch(kp.T * p.n_views))
@@ -2100,7 +2171,7 @@ T4D_EXPORT int t4d_fetch_status(const T4DProblem *prob, const void *state, T4DSt
     out->max_pairs_per_view = hs.max_pairs;
     out->total_pairs = (int64_t)hs.total_pairs;
     out->overflow = (int32_t)hs.overflow;
-    out->reserved = 0;
+    out->max_tile_pairs = (int32_t)min(hs.max_tile_pairs, 0x7fffffffu);
     return T4D_OK;
 }
 

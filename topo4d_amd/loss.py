@@ -94,3 +94,52 @@ def photometric_loss(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tensor = N
     """Per-view loss [V] for im, gt [V,3,H,W] (cam_m, cam_c [V,3] optional) — train.py:310,315 fused on the GPU.
     Differentiable w.r.t. im, cam_m, cam_c."""
     return _FusedPhotometric.apply(im, gt, cam_m, cam_c)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# masked L1 of the dense pass (reference train.py:394-405, get_loss_dense with use_mask=True)
+# ------------------------------------------------------------------------------------------------------------
+def masked_l1_loss_torch(im: torch.Tensor, gt: torch.Tensor, filtered_mask: torch.Tensor) -> torch.Tensor:
+    """train.py:400-405 restated: masked copies of the render and the target, L1 sum over the number of masked ELEMENTS
+    (the mask image carries the same plane in its three channels; all of them count).  Pinned by tests/golden/g8."""
+    masked_index = filtered_mask == 1
+    masked_im = torch.zeros_like(im)
+    masked_im[masked_index] = im[masked_index]
+    masked_gt = torch.zeros_like(im)
+    masked_gt[masked_index] = gt[masked_index]
+    return (masked_im - masked_gt).abs().sum() / masked_index.sum()
+
+
+class _FusedMaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, gt, mask):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        if not im.is_cuda:
+            raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+        im_c, gt_c, m_c = im.float().contiguous(), gt.float().contiguous(), mask.float().contiguous()
+        V, _, H, W = im_c.shape
+        dev = im_c.device
+        loss = torch.empty(V, dtype=torch.float32, device=dev)
+        d_im = torch.empty_like(im_c)
+        nbytes = lib.t4d_masked_l1_scratch_bytes(V)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = lib.t4d_masked_l1_loss(V, H, W, p(im_c), p(gt_c), p(m_c), None, p(loss), p(d_im), p(scratch), nbytes,
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"t4d_masked_l1_loss failed (code {rc}): {_lib.last_error()}")
+        ctx.save_for_backward(d_im)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        (d_im,) = ctx.saved_tensors
+        return d_im * go.view(-1, 1, 1, 1), None, None
+
+
+def masked_l1_loss(im: torch.Tensor, gt: torch.Tensor, filtered_mask: torch.Tensor) -> torch.Tensor:
+    """Per-view masked L1 [V] for im, gt, filtered_mask [V,3,H,W] - train.py:394-405 fused on the GPU (loss + dL/dim in two
+    launches).  Differentiable w.r.t. im."""
+    return _FusedMaskedL1.apply(im, gt, filtered_mask)

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (T4D_ABI_VERSION, T4D_ERR_PAIR_OVERFLOW, T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC,
+from ._lib import (T4D_ABI_VERSION, T4D_ERR_PAIR_OVERFLOW, T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_NO_LONG_BINS,
                    T4D_FLAG_PREFILTERED, T4D_OK, T4D_VIEW_FLOATS, T4DBackwardIO, T4DForwardIO, T4DProblem,
                    T4DStatus)
 
@@ -51,6 +51,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # ------------------------------------------------------------------------------------------------------------
 _SYNC_MODE = "checked"
 _CAPACITY = {}          # (device_index, P, H, W) -> learned per-view pair capacity
+_LONGEST_BIN = {}       # (device_index, P, H, W) -> longest tile list a checked forward has reported for this scene size
 _AUTO = {}              # (device_index, P, H, W, views key) -> _AutoTrack of the "auto" sync mode
 _AUTO_MAX = 256         # camera sets tracked at a time
 _BATCH_LOG = None       # when a list: every ViewBatch that runs a forward is appended (loop.GraphedViews keeps the batches
@@ -275,6 +276,11 @@ class ViewBatch:
             flags |= T4D_FLAG_DEBUG_SYNC
         if self.prefiltered:
             flags |= T4D_FLAG_PREFILTERED
+        # tile lists of this scene size stayed well below the LDS sort buffer (2048) so far: skip the long-bin sort launch
+        # (a speed hint only - see include/topo4d_raster.h)
+        longest = _LONGEST_BIN.get((self.device.index, P, self.H, self.W))
+        if longest is not None and longest <= 1536:
+            flags |= T4D_FLAG_NO_LONG_BINS
         return T4DProblem(T4D_ABI_VERSION, self.V, P, self.H, self.W, self.sh_degree, M, self.scale_modifier,
                           cap, flags, 0)
 
@@ -360,6 +366,7 @@ class ViewBatch:
             # keep 1.5x head-room over what this scene needs so that lazy calls on nearby scenes fit
             want = _round_capacity(status.max_pairs_per_view)
             _CAPACITY[key] = max(want, cap if key in _CAPACITY else 0)
+            _LONGEST_BIN[key] = max(_LONGEST_BIN.get(key, 0), int(status.max_tile_pairs))
             if track is not None:
                 track.need = max(track.need, int(status.max_pairs_per_view))
         elif track is not None:
