@@ -224,7 +224,7 @@ int t4d_activate_backward(int64_t P, const float *unnorm_rotations, const float 
  * int32, colors [nver,c], image [h,w,c] in/out (zeros or a background), depth_buffer [h,w] in/out (the caller fills it
  * with -999999 like render.py:72).  Results are bit-identical to the reference, including its border-ring dilation
  * (mesh_core.cpp:211) and "first triangle wins on equal depth".  rows [row_begin,row_end) select a horizontal band of
- * the image (multi-GPU: one band per rank); pass 0,h for everything.  pair_capacity bounds the (triangle, 16x16 tile)
+ * the image (multi-GPU: one band per rank); pass 0,h for everything.  pair_capacity bounds the (triangle, 32x32 tile)
  * pairs; on T4D_ERR_PAIR_OVERFLOW *pairs_needed (host) holds the size to retry with.  Synchronises the stream once. */
 size_t t4d_texture_bake_scratch_bytes(int32_t h, int32_t w, int64_t pair_capacity);
 int t4d_texture_bake(const float *vertices, const int32_t *triangles, const float *colors, int32_t nver, int32_t ntri,

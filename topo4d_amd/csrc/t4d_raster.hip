@@ -2044,7 +2044,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     } else if ((p.flags & T4D_FLAG_ASYNC_STATUS) && status) {
         // no synchronisation: the 16-byte raw status block lands in the caller's PINNED host memory once the scan kernel
         // has run; the caller looks at it after an event of its own (topo4d_amd's "auto" sync mode does, one call later)
-        T4D_HIP(hipMemcpyAsync((void *)status, st + L.status, sizeof(DevStatus), hipMemcpyDeviceToHost, stream));
+        T4D_HIP(hipMemcpyAsync((void *)status, st + L.status, 16, hipMemcpyDeviceToHost, stream));     // the documented 16 bytes
     }
     { ProfScope ps_(stream, K_SCATTER);
     hipLaunchKernelGGL(k_scatter, dim3(gP.x + (kp.T + kBlock - 1) / kBlock, p.n_views), dim3(kBlock), 0, stream, kp);

@@ -8,9 +8,11 @@
 // The reference walks the triangles serially and z-tests with a strict `>`, so a texel ends up with the triangle
 // of maximum interpolated depth and, among equals, the LOWEST index (for Topo4D every depth is 0: first triangle
 // wins).  That final state is order-independent, which is what makes a parallel formulation exact:
-//   k_tex_count / k_tex_scan / k_tex_fill   bin triangles by the 16x16-texel tiles their clipped pixel bbox touches
-//   k_tex_render                            one workgroup per tile, one thread per texel: gather the tile's triangles
-//                                           through LDS and keep the lexicographic max of (depth, -index)
+//   k_tex_count / k_tex_scan / k_tex_fill   bin triangles by the 32x32-texel tiles their clipped pixel bbox touches
+//                                           (one atomic per pair; the scan runs in 1024-bin chunks on as many workgroups)
+//   k_tex_render                            one workgroup per tile: like the reference, a triangle visits only the texels of
+//                                           its bounding box (a wave per triangle, lanes over the box), and the texels keep the
+//                                           lexicographic max of (depth, -index) through an LDS 64-bit integer maximum
 // including the reference's quirk that texels in the 2-pixel border ring of the image are drawn from any triangle
 // whose bbox contains them, with extrapolated barycentrics (mesh_core.cpp:211).
 // All arithmetic is written in the reference's operation order with FP contraction off.
@@ -25,9 +27,21 @@ int t4d_internal_fail(int code, const char *fmt, const char *a);
 
 namespace {
 
-constexpr int kTile = 16;
+constexpr int kTile = 32;        // bin = workgroup tile: 32x32 texels, four per thread (the dependent-load chain of a workgroup -
+                                 // bin header -> records -> colours - is then paid once per 1024 texels: at 16x16 the kernel was bound by it)
 constexpr int kBlock = 256;
-constexpr int kStage = 128;      // triangles staged in LDS per round
+constexpr int kStage = 128;      // triangles set up in LDS per round
+
+struct Tri {                                // 80 bytes = five 16-byte words: the unit of the per-tile lists
+    float p0x, p0y, v0x, v0y, v1x, v1y;     // p0, v0 = p2 - p0, v1 = p1 - p0
+    float dot00, dot01, dot11, inverDeno;
+    float d0, d1, d2;
+    int x_min, x_max, y_min, y_max;
+    int idx;
+    int i0, i1;                             // (pads the record to five 16-byte words)
+};
+static_assert(sizeof(Tri) == 80, "Tri must stay five float4 words");
+constexpr int kScanChunk = 1024;
 
 struct TexP {
     const float *vertices;
@@ -35,18 +49,11 @@ struct TexP {
     const float *colors;
     int nver, ntri, h, w, c, row_begin, row_end;
     int bx, by, by0;              // bins in x, bins in y inside the row band, first bin row of the band
+    int n_chunks;
     uint32_t cap;
-    uint32_t *bin_count, *bin_cursor, *bin_off, *list;
+    uint32_t *bin_count, *bin_cursor, *bin_off, *chunk_sum, *list;
     unsigned long long *total;
     float *image, *depth;
-};
-
-struct Tri {
-    float p0x, p0y, v0x, v0y, v1x, v1y;     // p0, v0 = p2 - p0, v1 = p1 - p0
-    float dot00, dot01, dot11, inverDeno;
-    float d0, d1, d2;
-    int x_min, x_max, y_min, y_max;
-    int idx;
 };
 
 // pixel bbox exactly as mesh_core.cpp:190-199, additionally clipped to the row band
@@ -76,40 +83,58 @@ __global__ __launch_bounds__(kBlock) void k_tex_count(const TexP P)
         for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&P.bin_count[by * P.bx + bx], 1u);
 }
 
-__global__ __launch_bounds__(1024) void k_tex_scan(const TexP P)
+__global__ __launch_bounds__(kScanChunk) void k_tex_chunk_sums(const TexP P)
+{
+    __shared__ uint32_t s_w[kScanChunk / 64];
+    const int c = blockIdx.x, tid = threadIdx.x, b = c * kScanChunk + tid;
+    uint32_t x = b < P.bx * P.by ? P.bin_count[b] : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d, 64);
+    if ((tid & 63) == 0) s_w[tid >> 6] = x;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kScanChunk / 64; w++) tot += s_w[w];
+        P.chunk_sum[c] = tot;
+    }
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_tex_scan(const TexP P)
 {
     __shared__ uint32_t s_w[16];
     __shared__ unsigned long long s_carry;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int chunk = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = P.bx * P.by;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
-        const int b = base + tid;
-        const uint32_t c = b < nb ? P.bin_count[b] : 0u;
-        uint32_t incl = c;
+    if (wave == 0) {                                                // pairs in the chunks before this one
+        unsigned long long part = 0;
+        for (int i = lane; i < chunk; i += 64) part += P.chunk_sum[i];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t x = s_w[k];
-            if (k < wave) woff += x;
-            tot += x;
-        }
-        const unsigned long long carry = s_carry;
-        const unsigned long long off = carry + woff + incl - c;
-        if (b < nb) P.bin_off[b] = off > 0xffffffffull ? 0xffffffffu : (uint32_t)off;
-        __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
-        __syncthreads();
+        for (int d = 32; d > 0; d >>= 1)
+            part += ((unsigned long long)(uint32_t)__shfl_xor((int)(part >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)part, d, 64);
+        if (lane == 0) s_carry = part;
     }
-    if (tid == 0) *P.total = s_carry;
+    const int b = chunk * kScanChunk + tid;
+    const uint32_t c = b < nb ? P.bin_count[b] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = s_w[k];
+        if (k < wave) woff += x;
+        tot += x;
+    }
+    const unsigned long long carry = s_carry;
+    const unsigned long long off = carry + woff + incl - c;
+    if (b < nb) P.bin_off[b] = off > 0xffffffffull ? 0xffffffffu : (uint32_t)off;
+    if (tid == 0 && chunk == P.n_chunks - 1) *P.total = carry + tot;
 }
 
 __global__ __launch_bounds__(kBlock) void k_tex_fill(const TexP P)
@@ -128,89 +153,176 @@ __global__ __launch_bounds__(kBlock) void k_tex_fill(const TexP P)
         }
 }
 
+// One workgroup per 32x32-texel tile.  The first version let every texel test every triangle of its tile (3.4 G tests for
+// the 8192^2 bake, 1.5 of its 2.1 ms, vector-ALU bound whatever the memory side did).  Like the reference, a triangle now only
+// visits the texels of its own bounding box:
+//   1. set-up: one lane per triangle of the round builds its record in LDS (parallel gathers);
+//   2. each wave takes records in turn and spreads the (bbox intersect tile) texels over its lanes; a texel that passes the
+//      reference's test with a depth above the caller's depth buffer enters an LDS ds_max_u64 with the key
+//      (order-preserving bits of its depth << 32 | ~triangle index): the maximum is the reference's final state - largest
+//      depth, lowest index among equals - whatever the order of arrival;
+//   3. every texel reads its winner and recomputes that one triangle's weights with the very same operations (bit-identical
+//      to what the loop of step 2 saw), interpolates the colours and writes image + depth.
+__device__ __forceinline__ uint32_t depth_order_bits(const float d)      // a > b  <=>  bits(a) > bits(b); -0 counts as +0
+{
+    const uint32_t u = __float_as_uint(d + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct TriEval { float w0, w1, w2, pd; bool pass; };
+
+// mesh_core.cpp:201-216 for one (triangle record, texel): barycentric weights, the in-triangle / border-ring test, depth
+__device__ __forceinline__ TriEval eval_texel(const Tri &t, const float px, const float py, const bool border)
+{
+#pragma clang fp contract(off)
+    TriEval r;
+    const float v2x = px - t.p0x, v2y = py - t.p0y;
+    const float dot02 = t.v0x * v2x + t.v0y * v2y;
+    const float dot12 = t.v1x * v2x + t.v1y * v2y;
+    const float u = (t.dot11 * dot02 - t.dot01 * dot12) * t.inverDeno;
+    const float v = (t.dot00 * dot12 - t.dot01 * dot02) * t.inverDeno;
+    const bool in_tri = (u >= 0) && (v >= 0) && (u + v < 1);
+    r.pass = border || in_tri;
+    r.w0 = 1 - u - v; r.w1 = v; r.w2 = u;
+    r.pd = r.w0 * t.d0 + r.w1 * t.d1 + r.w2 * t.d2;
+    return r;
+}
+
+// mesh_core.cpp:186-208: the per-triangle quantities from its three vertices (x, y, depth)
+__device__ __forceinline__ void setup_from_vertices(const float x0, const float y0, const float x1, const float y1, const float x2,
+                                                    const float y2, const float d0, const float d1, const float d2, Tri &t)
+{
+#pragma clang fp contract(off)
+    t.p0x = x0; t.p0y = y0;
+    t.v0x = x2 - x0; t.v0y = y2 - y0;
+    t.v1x = x1 - x0; t.v1y = y1 - y0;
+    t.dot00 = t.v0x * t.v0x + t.v0y * t.v0y;
+    t.dot01 = t.v0x * t.v1x + t.v0y * t.v1y;
+    t.dot11 = t.v1x * t.v1x + t.v1y * t.v1y;
+    if (t.dot00 * t.dot11 - t.dot01 * t.dot01 == 0) t.inverDeno = 0;
+    else t.inverDeno = 1 / (t.dot00 * t.dot11 - t.dot01 * t.dot01);
+    t.d0 = d0; t.d1 = d1; t.d2 = d2;
+}
+
+__device__ __forceinline__ void setup_triangle(const TexP &P, const int i, Tri &t)
+{
+#pragma clang fp contract(off)
+    const int i0 = P.triangles[3 * (size_t)i], i1 = P.triangles[3 * (size_t)i + 1], i2 = P.triangles[3 * (size_t)i + 2];
+    const float x0 = P.vertices[3 * (size_t)i0], y0 = P.vertices[3 * (size_t)i0 + 1];
+    const float x1 = P.vertices[3 * (size_t)i1], y1 = P.vertices[3 * (size_t)i1 + 1];
+    const float x2 = P.vertices[3 * (size_t)i2], y2 = P.vertices[3 * (size_t)i2 + 1];
+    t.p0x = x0; t.p0y = y0;
+    t.v0x = x2 - x0; t.v0y = y2 - y0;
+    t.v1x = x1 - x0; t.v1y = y1 - y0;
+    t.dot00 = t.v0x * t.v0x + t.v0y * t.v0y;
+    t.dot01 = t.v0x * t.v1x + t.v0y * t.v1y;
+    t.dot11 = t.v1x * t.v1x + t.v1y * t.v1y;
+    if (t.dot00 * t.dot11 - t.dot01 * t.dot01 == 0) t.inverDeno = 0;
+    else t.inverDeno = 1 / (t.dot00 * t.dot11 - t.dot01 * t.dot01);
+    t.d0 = P.vertices[3 * (size_t)i0 + 2]; t.d1 = P.vertices[3 * (size_t)i1 + 2]; t.d2 = P.vertices[3 * (size_t)i2 + 2];
+    t.x_min = max((int)ceilf(fminf(x0, fminf(x1, x2))), 0);
+    t.x_max = min((int)floorf(fmaxf(x0, fmaxf(x1, x2))), P.w - 1);
+    t.y_min = max((int)ceilf(fminf(y0, fminf(y1, y2))), 0);
+    t.y_max = min((int)floorf(fmaxf(y0, fmaxf(y1, y2))), P.h - 1);
+    t.idx = i; t.i0 = i0; t.i1 = i1;
+}
+
 __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
 {
 #pragma clang fp contract(off)
-    __shared__ Tri s_tri[kStage];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) Tri s_tri[kStage];
+    __shared__ unsigned long long s_key[kTile * kTile];
+    __shared__ float s_depth[kTile * kTile];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const int bxi = b % P.bx, byi = b / P.bx + P.by0;
     const uint32_t n = P.bin_count[b];
     if (n == 0) return;
     const uint32_t off = P.bin_off[b];
-    const int x = bxi * kTile + (tid & 15), y = byi * kTile + (tid >> 4);
-    const bool inside_img = x < P.w && y < P.h && y >= P.row_begin && y < P.row_end;
-    const float px = (float)x, py = (float)y;
-    const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;      // mesh_core.cpp:211
-    float best_d = inside_img ? P.depth[(size_t)y * P.w + x] : 0.f;
-    bool has = false;
-    int best_i = 0x7fffffff;
-    float bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
-
+    const int tx0 = bxi * kTile, ty0 = byi * kTile;
+    // rows of the tile that belong to this call's band and to the image
+    const int ry_lo = max(ty0, P.row_begin), ry_hi = min(min(ty0 + kTile, P.h), P.row_end) - 1, rx_hi = min(tx0 + kTile, P.w) - 1;
+    for (int e = tid; e < kTile * kTile; e += kBlock) {           // the caller's depth buffer for this tile: read once, tested from LDS
+        const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+        s_key[e] = 0ull;
+        s_depth[e] = (x <= rx_hi && y >= ry_lo && y <= ry_hi) ? P.depth[(size_t)y * P.w + x] : 0.f;
+    }
     for (uint32_t base = 0; base < n; base += kStage) {
         const int cnt = (int)min((uint32_t)kStage, n - base);
         __syncthreads();
-        if (tid < cnt && off + base + tid < P.cap) {
-            const int i = (int)P.list[off + base + tid];
-            const int i0 = P.triangles[3 * (size_t)i], i1 = P.triangles[3 * (size_t)i + 1], i2 = P.triangles[3 * (size_t)i + 2];
-            const float x0 = P.vertices[3 * (size_t)i0], y0 = P.vertices[3 * (size_t)i0 + 1];
-            const float x1 = P.vertices[3 * (size_t)i1], y1 = P.vertices[3 * (size_t)i1 + 1];
-            const float x2 = P.vertices[3 * (size_t)i2], y2 = P.vertices[3 * (size_t)i2 + 1];
+        if (tid < cnt) {
             Tri t;
-            t.p0x = x0; t.p0y = y0;
-            t.v0x = x2 - x0; t.v0y = y2 - y0;
-            t.v1x = x1 - x0; t.v1y = y1 - y0;
-            t.dot00 = t.v0x * t.v0x + t.v0y * t.v0y;
-            t.dot01 = t.v0x * t.v1x + t.v0y * t.v1y;
-            t.dot11 = t.v1x * t.v1x + t.v1y * t.v1y;
-            if (t.dot00 * t.dot11 - t.dot01 * t.dot01 == 0) t.inverDeno = 0;
-            else t.inverDeno = 1 / (t.dot00 * t.dot11 - t.dot01 * t.dot01);
-            t.d0 = P.vertices[3 * (size_t)i0 + 2]; t.d1 = P.vertices[3 * (size_t)i1 + 2]; t.d2 = P.vertices[3 * (size_t)i2 + 2];
-            t.x_min = max((int)ceilf(fminf(x0, fminf(x1, x2))), 0);
-            t.x_max = min((int)floorf(fmaxf(x0, fmaxf(x1, x2))), P.w - 1);
-            t.y_min = max((int)ceilf(fminf(y0, fminf(y1, y2))), 0);
-            t.y_max = min((int)floorf(fmaxf(y0, fmaxf(y1, y2))), P.h - 1);
-            t.idx = i;
-            s_tri[tid] = t;
-        } else if (tid < cnt) {
-            Tri t;
-            memset(&t, 0, sizeof(t));
-            t.x_min = 1; t.x_max = 0; t.y_min = 1; t.y_max = 0; t.idx = 0x7fffffff;     // matches no texel
+            if (off + base + tid < P.cap) setup_triangle(P, (int)P.list[off + base + tid], t);
+            else { memset(&t, 0, sizeof(t)); t.x_min = 1; t.x_max = 0; t.y_min = 1; t.y_max = 0; t.idx = 0x7fffffff; }     // matches no texel
             s_tri[tid] = t;
         }
         __syncthreads();
-        if (!inside_img) continue;
-        for (int k = 0; k < cnt; k++) {
-            const Tri &t = s_tri[k];
-            if (x < t.x_min || x > t.x_max || y < t.y_min || y > t.y_max) continue;
-            const float v2x = px - t.p0x, v2y = py - t.p0y;
-            const float dot02 = t.v0x * v2x + t.v0y * v2y;
-            const float dot12 = t.v1x * v2x + t.v1y * v2y;
-            const float u = (t.dot11 * dot02 - t.dot01 * dot12) * t.inverDeno;
-            const float v = (t.dot00 * dot12 - t.dot01 * dot02) * t.inverDeno;
-            const bool in_tri = (u >= 0) && (v >= 0) && (u + v < 1);
-            if (!(border || in_tri)) continue;
-            const float w0 = 1 - u - v, w1 = v, w2 = u;
-            const float pd = w0 * t.d0 + w1 * t.d1 + w2 * t.d2;
-            // serial `if (pd > depth)` over ascending triangle index == lexicographic max of (depth, -index)
-            if (pd > best_d || (has && pd == best_d && t.idx < best_i)) {
-                best_d = pd; best_i = t.idx; has = true;
-                bw0 = w0; bw1 = w1; bw2 = w2;
+        for (int k = wave; k < cnt; k += kBlock / 64) {           // wave-uniform: one record per wave at a time
+            const Tri t = s_tri[k];
+            const int x_lo = max(t.x_min, tx0), x_hi = min(t.x_max, rx_hi), y_lo = max(t.y_min, ry_lo), y_hi = min(t.y_max, ry_hi);
+            const int rw = x_hi - x_lo + 1, rh = y_hi - y_lo + 1;
+            if (rw <= 0 || rh <= 0) continue;
+            const int npx = rw * rh;
+            for (int p = lane; p < npx; p += 64) {
+                const int dy = p / rw, x = x_lo + (p - dy * rw), y = y_lo + dy;
+                const float px = (float)x, py = (float)y;
+                const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;      // mesh_core.cpp:211
+                const TriEval ev = eval_texel(t, px, py, border);
+                // `pd > depth_buffer` against the caller's buffer first (also drops NaN); later rivals meet in the LDS maximum
+                if (ev.pass && ev.pd > s_depth[(y - ty0) * kTile + (x - tx0)])
+                    atomicMax(&s_key[(y - ty0) * kTile + (x - tx0)],
+                              ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~(uint32_t)t.idx);
             }
         }
     }
-    if (inside_img && has) {
-        const int i0 = P.triangles[3 * (size_t)best_i], i1 = P.triangles[3 * (size_t)best_i + 1], i2 = P.triangles[3 * (size_t)best_i + 2];
+    __syncthreads();
+    // The image is [h, w, c]: a texel's c floats sit 4c bytes from its neighbour's; consecutive lanes therefore take
+    // consecutive texels of a tile row (the stores of a wave cover whole cache lines between them).
+    // Four texels per thread, their dependent gathers (triangle -> vertices -> colours) issued level by level for all four:
+    // the chain's latency is paid once per workgroup, not once per texel.
+    constexpr int kPer = kTile * kTile / kBlock;
+    int wi[kPer], wv[kPer][3];
+    bool hit[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const unsigned long long key = s_key[tid + j * kBlock];
+        hit[j] = key != 0ull;                                      // nobody drew this texel: the caller's background stays
+        wi[j] = hit[j] ? (int)~(uint32_t)key : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; j++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) wv[j][m] = hit[j] ? P.triangles[3 * (size_t)wi[j] + m] : 0;
+    float vx[kPer][3], vy[kPer][3], vz[kPer][3];
+#pragma unroll
+    for (int j = 0; j < kPer; j++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            vx[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m]] : 0.f;
+            vy[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m] + 1] : 0.f;
+            vz[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m] + 2] : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        if (!hit[j]) continue;
+        const int e = tid + j * kBlock;
+        const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+        Tri t;
+        setup_from_vertices(vx[j][0], vy[j][0], vx[j][1], vy[j][1], vx[j][2], vy[j][2], vz[j][0], vz[j][1], vz[j][2], t);
+        const float px = (float)x, py = (float)y;
+        const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;
+        const TriEval ev = eval_texel(t, px, py, border);
         float *out = P.image + ((size_t)y * P.w + x) * P.c;
         for (int k = 0; k < P.c; k++)
-            out[k] = bw0 * P.colors[(size_t)P.c * i0 + k] + bw1 * P.colors[(size_t)P.c * i1 + k] + bw2 * P.colors[(size_t)P.c * i2 + k];
-        P.depth[(size_t)y * P.w + x] = best_d;
+            out[k] = ev.w0 * P.colors[(size_t)P.c * wv[j][0] + k] + ev.w1 * P.colors[(size_t)P.c * wv[j][1] + k] +
+                     ev.w2 * P.colors[(size_t)P.c * wv[j][2] + k];
+        P.depth[(size_t)y * P.w + x] = ev.pd;
     }
 }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-struct TexLayout { size_t total_, bin_count, bin_cursor, zero_end, bin_off, list, bytes; };
+struct TexLayout { size_t total_, bin_count, bin_cursor, zero_end, bin_off, chunk_sum, list, bytes; };
 
 TexLayout tex_layout(int h, int w, int64_t cap)
 {
@@ -222,6 +334,7 @@ TexLayout tex_layout(int h, int w, int64_t cap)
     L.bin_cursor = o; o = align_up(o + nb * 4);
     L.zero_end = o;
     L.bin_off = o;    o = align_up(o + nb * 4);
+    L.chunk_sum = o;  o = align_up(o + ((nb + kScanChunk - 1) / kScanChunk) * 4);
     L.list = o;       o = align_up(o + (size_t)cap * 4);
     L.bytes = o;
     return L;
@@ -262,6 +375,8 @@ T4D_EXPORT int t4d_texture_bake(const float *vertices, const int32_t *triangles,
     P.bin_count = (uint32_t *)(sc + L.bin_count);
     P.bin_cursor = (uint32_t *)(sc + L.bin_cursor);
     P.bin_off = (uint32_t *)(sc + L.bin_off);
+    P.chunk_sum = (uint32_t *)(sc + L.chunk_sum);
+    P.n_chunks = (P.bx * P.by + kScanChunk - 1) / kScanChunk;
     P.list = (uint32_t *)(sc + L.list);
     P.image = image; P.depth = depth_buffer;
     if (pairs_needed) *pairs_needed = 0;
@@ -274,7 +389,8 @@ T4D_EXPORT int t4d_texture_bake(const float *vertices, const int32_t *triangles,
     TEX_HIP(hipMemsetAsync(sc, 0, L.zero_end, stream));
     const int gt = (ntri + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_tex_count, dim3(gt), dim3(kBlock), 0, stream, P);
-    hipLaunchKernelGGL(k_tex_scan, dim3(1), dim3(1024), 0, stream, P);
+    if (P.n_chunks > 1) hipLaunchKernelGGL(k_tex_chunk_sums, dim3(P.n_chunks), dim3(kScanChunk), 0, stream, P);
+    hipLaunchKernelGGL(k_tex_scan, dim3(P.n_chunks), dim3(kScanChunk), 0, stream, P);
     unsigned long long total = 0;
     TEX_HIP(hipMemcpyAsync(&total, P.total, 8, hipMemcpyDeviceToHost, stream));
     TEX_HIP(hipStreamSynchronize(stream));          // once per bake (a per-frame export step, not the training loop)
