@@ -981,6 +981,7 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
     for (int cc = 0; cc < NCHUNK; cc++) {
         const int c = REVERSE ? NCHUNK - 1 - cc : cc;
         const unsigned long long mw = m[c];
+        if (mw == 0ull) continue;                               // wave-uniform: most chunks of most batches are empty
         const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
         const int tot = __builtin_popcountll(mw);
         if ((mw >> lane) & 1ull) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)(((c << 6) + lane) * SCALE);
@@ -1253,12 +1254,13 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     constexpr int kSlabs = LAT ? 16 : 4;
     constexpr int kChunks = kBwdBatch / 64;
     constexpr int kListStride = kBwdBatch + 4;
-    constexpr int kEnt = 8;                  // list entries are slot * 8: byte offset into s_xy, half the offset into s_q / s_cd
+    // A staged splat is ONE 40-byte record - scaled conic + opacity (16) | rgb + depth (16) | xy (8) - exactly as long as a slab
+    // entry (ten floats), and list entries are slot * 40: the byte offset of BOTH, so a step spends no vector instruction on
+    // addresses (records are read as 8-byte words: a 40-byte stride keeps them 8- but not 16-byte aligned).
+    constexpr int kEnt = 40;
     static_assert(kGP == kAcc, "the slab entry and the scratch record hold the same ten sums");
-    static_assert(kAcc * 4 % kEnt == 0, "slab records must be a whole multiple of the entry scale");
-    __shared__ float2 s_xy[kBwdBatch + 1];
-    __shared__ float4 s_q[kBwdBatch + 1];    // scaled conic + opacity (alpha evaluation)
-    __shared__ float4 s_cd[kBwdBatch + 1];
+    static_assert(kAcc * 4 == kEnt, "a slab entry and a staged record must have the same stride");
+    __shared__ __attribute__((aligned(8))) unsigned char s_rec[(kBwdBatch + 1) * kEnt];
     __shared__ uint32_t s_pair[kBwdBatch];
     __shared__ __attribute__((aligned(8))) float s_acc[kSlabs][kBwdBatch + 1][kAcc];   // + the null splat's (never read) row
     __shared__ unsigned long long s_mask[16][kChunks];
@@ -1273,9 +1275,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     const int my_slot = (!DA && row10_index(lane & 15) == 9) ? -1 : row10_index(lane & 15);
     const bool sel_mid = (lane & 3) == 1, sel_hi = (lane & 3) == 2;
     if (tid == 0) {
-        s_xy[kNull] = make_float2(0.f, 0.f);
-        s_q[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_cd[kNull] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kEnt / 8; k++) reinterpret_cast<float2 *>(s_rec + kNull * kEnt)[k] = make_float2(0.f, 0.f);
     }
     for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
     for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {
@@ -1317,8 +1318,9 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     float T = T_final;
     // Suffix state of the replay.  Upstream keeps one running "colour behind me" per channel (+ depth, + alpha) and dots
     // it with dL/dpixel afterwards; the recursion is linear, so the dot product is taken FIRST and a single scalar is
-    // carried:  q_i = c_i . dL/dC (+ depth_i dL/dD + dL/dAlpha),  acc <- alpha_prev q_prev + (1 - alpha_prev) acc.
-    float acc = 0.f, last_q = 0.f, last_alpha = 0.f;
+    // carried:  q_i = c_i . dL/dC (+ depth_i dL/dD + dL/dAlpha),  acc <- alpha_i q_i + (1 - alpha_i) acc  once splat i is done
+    // (upstream applies the same update lazily, at the next contributor: same operands, same order, same bits).
+    float acc = 0.f;
     const float tf_bg = T_final * (vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2);
 
     const uint32_t rmax_v = row_max_u32(last_contributor);
@@ -1353,10 +1355,12 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             s_pair[tid] = (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) ? pair_off[g] + (uint32_t)local : 0xffffffffu;
             if (live) {
                 const float4 c = co[g];
-                s_xy[tid] = p;
-                s_q[tid] = scale_conic(c);
-                s_cd[tid] = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
-                                        __uint_as_float((uint32_t)(key >> 32)));
+                const float4 q4 = scale_conic(c);
+                float2 *rec = reinterpret_cast<float2 *>(s_rec + tid * kEnt);
+                rec[0] = make_float2(q4.x, q4.y); rec[1] = make_float2(q4.z, q4.w);
+                rec[2] = make_float2(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1]);
+                rec[3] = make_float2(rgb[3 * (size_t)g + 2], __uint_as_float((uint32_t)(key >> 32)));
+                rec[4] = p;
                 touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
             }
         }
@@ -1408,14 +1412,12 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #pragma unroll
             for (int c2 = 0; c2 < kChunks; c2++) conflict_s[c2] = uniform_u64(conflict[c2]);
             const unsigned short *list = s_list[wave][row];
-            const unsigned char *xy_b = reinterpret_cast<const unsigned char *>(s_xy);
-            const unsigned char *q_b = reinterpret_cast<const unsigned char *>(s_q);
-            const unsigned char *cd_b = reinterpret_cast<const unsigned char *>(s_cd);
+            const unsigned char *rec_b = s_rec;
             // LAT: lanes that keep no sum write (zeros plus whatever) into distinct floats of the null splat's row of their slab
             unsigned char *slab = LAT ? reinterpret_cast<unsigned char *>(my_slot >= 0 ? &s_acc[wave * 4 + row][0][my_slot]
                                                                                       : &s_acc[wave * 4 + row][kNull][(lane & 15) % kAcc])
                                       : reinterpret_cast<unsigned char *>(&s_acc[wave][0][0] + (my_slot >= 0 ? my_slot : 0));
-            const uint32_t slab_mul = (!LAT || my_slot >= 0) ? (uint32_t)(kAcc * 4 / kEnt) : 0u;
+            const uint32_t slab_and = (!LAT || my_slot >= 0) ? 0xffffffffu : 0u;       // slot-less lanes of the latency build stay on their dummy float
             // entry of the first staged splat this pixel did NOT see in the forward pass (entries are slot * kEnt)
             const int lc_rel = (int)min(last_contributor - min(last_contributor, lo), (uint32_t)kBwdBatch) * kEnt;
 #if T4D_ABL == 3
@@ -1439,10 +1441,12 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                 bool contribs[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {            // four independent evaluations (ILP)
-                    ds[u] = *reinterpret_cast<const v2f *>(xy_b + ee[u]) - pix_f;
-                    cds[u] = *reinterpret_cast<const float4 *>(cd_b + 2 * ee[u]);
+                    const float2 *rec = reinterpret_cast<const float2 *>(rec_b + ee[u]);
+                    const float2 q01 = rec[0], q23 = rec[1], c01 = rec[2], c23 = rec[3];
+                    ds[u] = *reinterpret_cast<const v2f *>(rec + 4) - pix_f;
+                    cds[u] = make_float4(c01.x, c01.y, c23.x, c23.y);
                     float p2;
-                    eval_splat(*reinterpret_cast<const float4 *>(q_b + 2 * ee[u]), ds[u], p2, Gs[u], alphas[u]);
+                    eval_splat(make_float4(q01.x, q01.y, q23.x, q23.y), ds[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
                 }
                 const uint32_t cbits = (uint32_t)(conflict_s[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63));
@@ -1451,7 +1455,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     const bool contrib = contribs[u];
                     const v2f d = ds[u];
                     const float G = Gs[u], alpha = alphas[u];
-                    float *dst = reinterpret_cast<float *>(slab + __umul24(ee[u], slab_mul));
+                    float *dst = reinterpret_cast<float *>(slab + (LAT ? (ee[u] & slab_and) : ee[u]));
                     const float old = *dst;              // early read of the slab value this step adds to
                     float e = 0.f, w = 0.f;
 #if T4D_ABL == 2
@@ -1462,34 +1466,31 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         // the same operations in the same order as the exec-masked region below, on every lane; the selects keep
                         // the state of the lanes that do not contribute
                         const float4 cd = cds[u];
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        const float om = 1.f - alpha;
+                        const float inv = __builtin_amdgcn_rcpf(om);
                         const float Tn = T * inv;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
-                        const float accn = fmaf(last_alpha, last_q, (1.f - last_alpha) * acc);
-                        const float dL_dalpha = fmaf(q - accn, Tn, -tf_bg * inv);
+                        const float dL_dalpha = fmaf(q - acc, Tn, -tf_bg * inv);
                         T = contrib ? Tn : T;
                         w = contrib ? alpha * Tn : 0.f;
-                        acc = contrib ? accn : acc;
-                        last_q = contrib ? q : last_q;
-                        last_alpha = contrib ? alpha : last_alpha;
                         e = contrib ? G * dL_dalpha : 0.f;
+                        acc = contrib ? fmaf(alpha, q, om * acc) : acc;
                     } else if (contrib) {
 #endif
                         // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
                         // the splat centre, and w * dL/dC.  Everything that is constant per splat (opacity, conic,
                         // 0.5*W, -0.5 ...) is applied ONCE per Gaussian after all tiles are summed (k_preprocess_bwd).
                         const float4 cd = cds[u];
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);     // 1 - alpha >= 0.01
+                        const float om = 1.f - alpha;                              // >= 0.01
+                        const float inv = __builtin_amdgcn_rcpf(om);
                         T = T * inv;
                         w = alpha * T;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
-                        acc = fmaf(last_alpha, last_q, (1.f - last_alpha) * acc);
-                        last_q = q;
-                        last_alpha = alpha;
-                        const float dL_dalpha = fmaf(q - acc, T, -tf_bg * inv);
+                        const float dL_dalpha = fmaf(q - acc, T, -tf_bg * inv);    // acc = the colour behind THIS splat
                         e = G * dL_dalpha;
+                        acc = fmaf(alpha, q, om * acc);                            // ... and now behind the next one towards the eye
                     }
                     // lanes that do not contribute carry e = w = 0, so their ten products are exact zeros
                     const v2f ed = e * d, edd = ed * d, wdp = w * dp01;
