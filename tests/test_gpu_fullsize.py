@@ -274,10 +274,13 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
         # an abrupt jump (scales x6 from one call to the next) overflows once and is REPORTED at the following call
         rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()
         call(R[0]); call(R[0])
-        call(R[0], 6.0)
+        leaf = d["means3D"].clone().requires_grad_(True)
+        out_t = R[0](leaf, None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * 6.0, rotations=d["rotations"])
+        out_t[0].sum().backward()
         torch.cuda.synchronize()
-        with pytest.raises(RuntimeError, match="truncated"):
-            call(R[0], 6.0)
+        assert not leaf.grad.any()                            # the truncated pass is benign: zero gradients, never garbage
+        with pytest.raises(RuntimeError, match="truncated"):  # ... and it is reported before the optimiser would step
+            topo4d_amd.poll_truncation()
         out = call(R[0], 6.0)                                  # arena was enlarged: now complete again
         topo4d_amd.set_sync_mode("checked")
         for a, b in zip(out, call(R[0], 6.0)):
