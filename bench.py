@@ -61,7 +61,7 @@ def cpu_baseline(cfg, n_sample_views, reps):
     """C oracle (oracle/raster_oracle.c), OpenMP over all host cores, fwd+bwd on a bounded sample of the workload; min of
     `reps` repetitions (SURVEY.md §8d asks for min-of-5)."""
     from oracle import c_oracle as CO
-    from topo4d_amd import boundary, scene
+    from scaffold import reference_boundary as boundary, scene
     CO.build()
     params = scene.make_gaussians(cfg["n_lat"], cfg["n_lon"], opacity="A", sh_degree=cfg["sh_degree"], seed=0)
     rv = {k: v.detach() for k, v in boundary.params2rendervar(params).items()}
@@ -135,7 +135,8 @@ class Workload:
     loss scalars + (N > 1) their asynchronous all_gather."""
 
     def __init__(self, cfgname, opacity, dev, rank=0, world=1, n_streams=1, n_frames=64, resident=8):
-        from topo4d_amd import ViewBatch, boundary, dist as t4d_dist, pack_views, scene
+        from scaffold import reference_boundary as boundary, scene
+        from topo4d_amd import ViewBatch, dist as t4d_dist, pack_views
         self.t4d_dist = t4d_dist
         self.cfg = cfg = dict(scene.CONFIGS[cfgname])
         self.dev, self.rank, self.world = dev, rank, world
@@ -281,7 +282,8 @@ def single_view_probe(dev):
     """The reference's own call shape (train.py:661-673): ONE camera per call, P = 8,280, 512x375.  GPU time per forward +
     backward = sum of the HIP-event durations of the rasterizer's kernels; wall time per un-synchronised call pair too."""
     import topo4d_amd
-    from topo4d_amd import ViewBatch, _lib, boundary, pack_views, scene
+    from scaffold import reference_boundary as boundary, scene
+    from topo4d_amd import ViewBatch, _lib, pack_views
     H, W = 512, 375                                                    # helpers.py:807: (3, 512, 375) images
     p = scene.make_gaussians(69, 120, opacity="A", seed=0)             # 8,280 vertex-bound Gaussians
     cams = scene.camera_rig(H, W, n_views=24, device=dev)

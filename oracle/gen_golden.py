@@ -218,7 +218,7 @@ def main():
 
     # ---- G6 (self-generated) --------------------------------------------------------------------------------
     from oracle import torch_oracle as TO
-    from topo4d_amd import boundary, scene
+    from scaffold import reference_boundary as boundary, scene
     p = scene.make_gaussians(10, 20, opacity="B", seed=6)
     rvv = {k: v.detach() for k, v in boundary.params2rendervar(p).items()}
     cam = scene.camera_rig(64, 64, n_views=3)[1]

@@ -15,7 +15,7 @@ from typing import Dict, List
 import numpy as np
 import torch
 
-from .boundary import setup_camera
+from .reference_boundary import setup_camera
 
 # BASELINE.json configs -> (n_lat, n_lon, H, W, sh_degree)
 CONFIGS = {

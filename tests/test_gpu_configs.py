@@ -53,7 +53,7 @@ def _bins_ok(st, v, P, radii_v, gx, gy, sample_tiles=None):
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opacity", ["A", "B"])
 def test_c4_full_size_sh3(opacity):
-    from topo4d_amd import scene
+    from scaffold import scene
     cfg = scene.CONFIGS["C4"]
     H, W, V = cfg["H"], cfg["W"], cfg["n_views"]
     rv, cams = util.make_scene(cfg["n_lat"], cfg["n_lon"], H, W, V, opacity=opacity, sh_degree=cfg["sh_degree"], seed=0)
@@ -103,7 +103,7 @@ def test_c4_full_size_sh3(opacity):
 # config 2, scenario B, full size
 # ------------------------------------------------------------------------------------------------------------------
 def test_c2_full_size_scenario_b():
-    from topo4d_amd import scene
+    from scaffold import scene
     cfg = scene.CONFIGS["C2"]
     H, W, V = cfg["H"], cfg["W"], cfg["n_views"]
     rv, cams = util.make_scene(cfg["n_lat"], cfg["n_lon"], H, W, V, opacity="B", seed=0)
@@ -140,7 +140,8 @@ def test_dense_envelope_one_million_gaussians_through_the_drop_in():
     full-resolution ~4K images).  dense_means3D is a plain tensor (re-interpolated per frame, train.py:259-261), opacities
     0.9999 and scales log(nn_dist) are Parameters with LR 0 (train.py:257,262,283-284)."""
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
-    from topo4d_amd import boundary, rasterizer, scene
+    from scaffold import reference_boundary as boundary, scene
+    from topo4d_amd import rasterizer
     H, W = 3008, 4096
     p = scene.make_gaussians(1000, 1000, opacity="A", seed=0)
     P = p["means3D"].shape[0]
@@ -225,7 +226,7 @@ def test_c5_texture_bake_8192_bit_identical_to_reference_code():
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("trial", range(12))
 def test_randomised_scenes_against_c_oracle(trial):
-    from topo4d_amd import scene
+    from scaffold import scene
     rng = np.random.default_rng(1000 + trial)
     H, W = int(rng.integers(40, 150)), int(rng.integers(40, 150))
     V = 2
@@ -265,7 +266,7 @@ def _unproject(cam, px, py, z):
 def test_culling_edges_opacity_at_one_over_255():
     """Opacities within a few ulp of 1/255 (alpha can reach the threshold only at the very centre), and just below it
     (never drawn - Topo4D's eye interior is 1e-6, train.py:626)."""
-    from topo4d_amd import scene
+    from scaffold import scene
     H = W = 96
     cam = scene.camera_rig(H, W, n_views=3)[1]
     g = torch.Generator().manual_seed(5)
@@ -292,7 +293,7 @@ def test_culling_edges_opacity_at_one_over_255():
 def test_culling_edges_needles_and_sub_block_corners():
     """Needle-shaped splats (conic eigenvalue ratio >> 1) in every orientation, centred ON the corners and edges of the 4x4
     sub-blocks the render kernels cull by, plus fat splats whose cut-off circle grazes sub-block corners."""
-    from topo4d_amd import scene
+    from scaffold import scene
     H = W = 128
     cams = scene.camera_rig(H, W, n_views=3)[:2]
     g = torch.Generator().manual_seed(9)

@@ -17,7 +17,8 @@ def test_drop_in_module_autograd_through_topo4d_activations():
     LEAF Parameters (train.py:303-315,667) vs float64 autograd through the same activations on the CPU oracle."""
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
     from oracle import torch_oracle as TO
-    from topo4d_amd import boundary, loss, scene
+    from scaffold import reference_boundary as boundary, scene
+    from topo4d_amd import loss
     H = W = 64
     p_cpu = scene.make_gaussians(12, 20, opacity="B", seed=3)
     cams_cpu = scene.camera_rig(H, W, n_views=3)
@@ -60,7 +61,8 @@ def test_drop_in_module_autograd_through_topo4d_activations():
 
 def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypatch):
     import topo4d_amd
-    from topo4d_amd import rasterizer, scene
+    from scaffold import scene
+    from topo4d_amd import rasterizer
     H = W = 96
     rv, cams = util.make_scene(20, 32, H, W, 3, opacity="B", seed=4)
     dc, _, _ = scene.output_cotangents(3, H, W, seed=5)
@@ -116,7 +118,7 @@ def test_view_dot_and_mark_visible():
 @pytest.fixture(scope="module")
 def c2():
     """BASELINE config 2, both output cotangents; rendered once for the tests below."""
-    from topo4d_amd import scene
+    from scaffold import scene
     cfg = scene.CONFIGS["C2"]
     rv, cams = util.make_scene(cfg["n_lat"], cfg["n_lon"], cfg["H"], cfg["W"], cfg["n_views"], opacity="A", seed=0)
     dc, dd, da = scene.output_cotangents(cfg["n_views"], cfg["H"], cfg["W"], seed=0, depth_alpha=True)
@@ -203,7 +205,7 @@ def test_module_accepts_what_upstream_accepts():
     (train.py:463,484), all through the drop-in module."""
     import topo4d_amd
     from oracle import torch_oracle as TO
-    from topo4d_amd import scene
+    from scaffold import scene
     H = W = 64
     rv, cams = util.make_scene(10, 16, H, W, 2, opacity="B", seed=8)
     cam = util.to_device(cams, "cuda")[0]
@@ -237,7 +239,8 @@ def test_module_accepts_what_upstream_accepts():
 
 def test_auto_sync_mode_tracks_capacity_without_syncing():
     import topo4d_amd
-    from topo4d_amd import rasterizer, scene
+    from scaffold import scene
+    from topo4d_amd import rasterizer
     H = W = 96
     rv, cams = util.make_scene(20, 32, H, W, 2, opacity="B", seed=4)
     dcams = util.to_device(cams, "cuda")

@@ -53,7 +53,8 @@ def test_fused_adam_matches_torch_adam_and_pins():
 def test_per_view_loop_fused_vs_torch_pieces():
     import topo4d_amd
     from tests import util
-    from topo4d_amd import loop, scene
+    from scaffold import scene
+    from topo4d_amd import loop
     from topo4d_amd.optim import FusedAdamPins
     H = W = 64
     p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)
@@ -86,14 +87,15 @@ def test_per_view_loop_fused_vs_torch_pieces():
 
 def test_fused_activations_match_torch():
     """t4d_activate_forward/backward vs torch's normalize / sigmoid / exp and their autograd (helpers.py:95-97)."""
-    from topo4d_amd import boundary, scene
+    from scaffold import reference_boundary as boundary, scene
     torch.manual_seed(3)
     p = scene.make_gaussians(12, 20, opacity="B", seed=5)
     p["unnorm_rotations"] = p["unnorm_rotations"] * (0.2 + 3 * torch.rand(p["unnorm_rotations"].shape[0], 1))   # not unit length
     p["unnorm_rotations"][3] = 0.0                                                                      # the eps-clamped branch
     pa = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p.items()}
     pb = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p.items()}
-    ra, rb = boundary.params2rendervar(pa), boundary.params2rendervar_fused(pb)
+    from topo4d_amd.boundary import params2rendervar_fused
+    ra, rb = boundary.params2rendervar(pa), params2rendervar_fused(pb)
     for k in ("rotations", "opacities", "scales"):
         assert rb[k].shape == ra[k].shape
         torch.testing.assert_close(rb[k], ra[k], rtol=2e-6, atol=1e-7)
@@ -104,7 +106,7 @@ def test_fused_activations_match_torch():
         torch.testing.assert_close(pb[k].grad, pa[k].grad, rtol=2e-5, atol=1e-6)
     # only some inputs need a gradient
     pc = {k: v.detach().clone().requires_grad_(k == "log_scales") for k, v in pb.items()}
-    rc = boundary.params2rendervar_fused(pc)
+    rc = params2rendervar_fused(pc)
     (rc["scales"] * g["scales"]).sum().backward()
     torch.testing.assert_close(pc["log_scales"].grad, pa["log_scales"].grad, rtol=2e-5, atol=1e-6)
     assert pc["unnorm_rotations"].grad is None
@@ -115,7 +117,8 @@ def test_graphed_views_replay_equals_the_eager_loop():
     same iterations issued eagerly, same camera schedule, changing a learning rate on the way."""
     import topo4d_amd
     from tests import util
-    from topo4d_amd import loop, scene
+    from scaffold import scene
+    from topo4d_amd import loop
     from topo4d_amd.optim import FusedAdamPins
     H = W = 64
     p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)

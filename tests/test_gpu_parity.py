@@ -88,7 +88,7 @@ def test_forward_backward_vs_c_oracle(opacity, render_build):
     H = W = 128
     V = 4
     rv, cams = util.make_scene(30, 50, H, W, V, opacity=opacity, seed=1)
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=2, depth_alpha=True)
     hip, hg, batch = util.hip_render(cams, rv, dc, dd, da)
     st = util.decode_state(batch)
@@ -121,7 +121,7 @@ def test_gradients_vs_autograd_f64(opacity, render_build):
     H = W = 96
     V = 2
     rv, cams = util.make_scene(20, 32, H, W, V, opacity=opacity, seed=5)
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=6, depth_alpha=True)
     hip, hg, _ = util.hip_render(cams, rv, dc, dd, da)
     for v in range(V):
@@ -139,7 +139,7 @@ def test_sh_colour_path(deg):
         pad = torch.randn(rv["shs"].shape[0], 3, 3) * 0.05
         rv["shs"] = torch.cat([rv["shs"], pad], dim=1).contiguous()
     rv["shs"][::7, 0, :] = -3.0     # force negative colours -> exercises the clamp flags
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=8, depth_alpha=True)
     hip, hg, _ = util.hip_render(cams, rv, dc, dd, da)
     for v in range(V):
@@ -161,7 +161,7 @@ def test_cov3d_precomp_path():
     S = RS @ RS.transpose(1, 2)
     rv["cov3D_precomp"] = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).float()
     del rv["scales"], rv["rotations"]
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, _, _ = scene.output_cotangents(V, H, W, seed=10)
     hip, hg, _ = util.hip_render(cams, rv, dc)
     for v in range(V):
@@ -177,7 +177,7 @@ def test_ragged_image_and_background(render_build):
     """512x375-style image (not a multiple of 16, helpers.py:807) and a non-zero background."""
     H, W, V = 75, 100, 3
     rv, cams = util.make_scene(16, 24, H, W, V, opacity="B", seed=11, bg=[0.2, 0.5, 0.9])
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=12, depth_alpha=True)
     hip, hg, _ = util.hip_render(cams, rv, dc, dd, da)
     for v in range(V):
@@ -201,7 +201,7 @@ def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch)
               scales=torch.rand(P, 3, generator=g) * 0.05 + 0.08,
               rotations=torch.nn.functional.normalize(torch.randn(P, 4, generator=g)),
               colors_precomp=torch.rand(P, 3, generator=g))
-    from topo4d_amd import scene
+    from scaffold import scene
     cams = scene.camera_rig(H, W, n_views=1)
     dc, dd, da = scene.output_cotangents(V, H, W, seed=4, depth_alpha=True)
     rasterizer._LONGEST_BIN.clear()
@@ -230,7 +230,7 @@ def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch)
 
 
 def test_degenerate_inputs():
-    from topo4d_amd import scene
+    from scaffold import scene
     H = W = 48
     cams = scene.camera_rig(H, W, n_views=2)
     # (a) a single Gaussian
@@ -261,7 +261,7 @@ def test_bitwise_determinism(render_build):
     H = W = 128
     V = 3
     rv, cams = util.make_scene(30, 50, H, W, V, opacity="B", seed=21)
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=22, depth_alpha=True)
     a, ga, _ = util.hip_render(cams, rv, dc, dd, da)
     b, gb, _ = util.hip_render(cams, rv, dc, dd, da)
@@ -276,7 +276,7 @@ def test_views_batched_equals_views_one_by_one(render_build):
     H = W = 96
     V = 5
     rv, cams = util.make_scene(20, 32, H, W, V, opacity="B", seed=31)
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, _, _ = scene.output_cotangents(V, H, W, seed=32)
     a, ga, _ = util.hip_render(cams, rv, dc)
     for v in range(V):
@@ -293,7 +293,7 @@ def test_latency_and_throughput_builds_agree(monkeypatch):
     backward adds the same partial sums in a different fixed order (one slab per DPP row instead of one per wave)."""
     H, W, V = 100, 75, 3
     rv, cams = util.make_scene(24, 40, H, W, V, opacity="B", seed=41)
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=42, depth_alpha=True)
     res = {}
     for name, lim in (("throughput", "0"), ("latency", "1000000000")):
@@ -320,7 +320,7 @@ def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
     rv, cams = util.make_scene(60, 80, H, W, V, opacity="B", seed=51)
     perm = torch.randperm(rv["means3D"].shape[0], generator=torch.Generator().manual_seed(1))
     rv = {k: v[perm].contiguous() for k, v in rv.items()}
-    from topo4d_amd import scene
+    from scaffold import scene
     dc, _, _ = scene.output_cotangents(V, H, W, seed=52)
     hip, hg, batch = util.hip_render(cams, rv, dc)
     st = util.decode_state(batch)

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 import topo4d_amd
-from topo4d_amd import _lib, boundary, rasterizer, scene
+from scaffold import reference_boundary as boundary, scene
+from topo4d_amd import _lib, rasterizer
 
 
 def _cam():

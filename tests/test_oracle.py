@@ -11,7 +11,7 @@ import torch
 from oracle import c_oracle as CO
 from oracle import torch_oracle as TO
 from tests import util
-from topo4d_amd import scene
+from scaffold import scene
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 KEYS = ("means3D", "means2D", "opacities", "scales", "rotations", "colors_precomp")
@@ -94,7 +94,7 @@ def test_autograd_oracle_against_finite_differences():
 
 def test_g6_fixture_pins_both_oracles():
     g = np.load(os.path.join(G, "g6_self_oracle_f64.npz"))
-    from topo4d_amd import boundary
+    from scaffold import reference_boundary as boundary
     p = scene.make_gaussians(10, 20, opacity="B", seed=6)
     rv = {k: v.detach() for k, v in boundary.params2rendervar(p).items()}
     cam = scene.camera_rig(64, 64, n_views=3)[1]

@@ -8,7 +8,7 @@ import torch
 
 from oracle import c_oracle as CO
 from oracle import torch_oracle as TO
-from topo4d_amd import boundary, scene
+from scaffold import reference_boundary as boundary, scene
 
 GRAD_KEYS = ("means3D", "means2D", "opacities", "scales", "rotations", "colors_precomp")
 

@@ -8,7 +8,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import topo4d_amd
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
-from topo4d_amd import boundary, loss, scene
+from scaffold import reference_boundary as boundary, scene
+from topo4d_amd import boundary as fused_boundary
+from topo4d_amd import loss
 
 dev = torch.device("cuda")
 H, W = 512, 375
@@ -43,7 +45,7 @@ def it_fused_all(i):
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
     l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); fopt.step(); fopt.zero_grad(set_to_none=True)
 def it_fused_all_act(i):
-    rv = boundary.params2rendervar_fused(params)
+    rv = fused_boundary.params2rendervar_fused(params)
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
     l = loss.photometric_loss(im[None], gts[i % 24][None]).sum(); l.backward(); fopt.step(); fopt.zero_grad(set_to_none=True)
 def it_torch_all(i):

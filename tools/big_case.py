@@ -5,7 +5,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import topo4d_amd
-from topo4d_amd import ViewBatch, boundary, pack_views, scene
+from scaffold import reference_boundary as boundary, scene
+from topo4d_amd import ViewBatch, pack_views
 import util
 dev = torch.device("cuda")
 H, W = 3008, 4096

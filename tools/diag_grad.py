@@ -4,7 +4,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import util
-from topo4d_amd import scene
+from scaffold import scene
 cfgname, opacity, view = sys.argv[1], sys.argv[2], int(sys.argv[3])
 cfg = scene.CONFIGS[cfgname]
 H, W, V = cfg["H"], cfg["W"], cfg["n_views"]

@@ -3,7 +3,7 @@ import cProfile, os, pstats, sys, io
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import topo4d_amd
-from topo4d_amd import boundary, scene
+from scaffold import reference_boundary as boundary, scene
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 dev = torch.device("cuda"); H, W = 512, 375
 p = scene.make_gaussians(69, 120, opacity="A", seed=0)

@@ -4,7 +4,8 @@ import os, sys, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import topo4d_amd
-from topo4d_amd import ViewBatch, _lib, boundary, pack_views, scene
+from scaffold import reference_boundary as boundary, scene
+from topo4d_amd import ViewBatch, _lib, pack_views
 dev = torch.device("cuda"); H, W = 512, 375
 p = scene.make_gaussians(69, 120, opacity="A", seed=0)
 cams = scene.camera_rig(H, W, n_views=24, device=dev)

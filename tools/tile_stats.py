@@ -5,7 +5,8 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from topo4d_amd import ViewBatch, boundary, pack_views, scene
+from scaffold import reference_boundary as boundary, scene
+from topo4d_amd import ViewBatch, pack_views
 import util
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C2"

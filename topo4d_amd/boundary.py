@@ -1,64 +1,13 @@
 """
-Host-side mirror of Topo4D's render boundary (reference helpers.py:63-112).
+Fused parameter activations of Topo4D's render boundary (reference helpers.py:91-100, `params2rendervar`): the same dictionary
+of rasterizer kwargs with `F.normalize` / `sigmoid` / `exp` and their autograd in one HIP launch each way
+(t4d_activate_forward / t4d_activate_backward) instead of ~15 tiny torch launches per iteration.  Opt-in.
 
-Topo4D keeps its own copies of these helpers; they are restated here, device-agnostic, because the
-synthetic-scene generator, bench.py and the tests have to build the SAME `GaussianRasterizationSettings`
-and the same rasterizer kwargs without importing the reference (which does not exist on the GPU box).
-Golden vectors captured from the real helpers (tests/golden/g1_setup_camera.npz, g2_params2rendervar.npz,
-generated by oracle/gen_golden.py) pin both functions.
+The plain mirrors of the reference helpers that the scene generator, bench and tests use live in scaffold/reference_boundary.py.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
-
-from .rasterizer import GaussianRasterizationSettings
-
-
-def setup_camera(w, h, k, w2c, near=0.01, far=100, device="cpu", true_campos=False):
-    """Mirror of helpers.py:63-88 `setup_camera(cam, w, h, k, w2c, near, far)` (minus the unused `cam`).
-
-    Matrices come out TRANSPOSED with a leading batch dim of 1 (helpers.py:67,71-72), i.e. flat
-    column-major as the kernels consume them.  `campos` reproduces the reference's quirk: it reads the
-    bottom row of inverse(w2c) (helpers.py:66), which is always (0,0,0).  Pass true_campos=True to get
-    the real camera centre instead (needed once view-dependent SH colours are used, BASELINE config 4).
-    """
-    fx, fy, cx, cy = k[0][0], k[1][1], k[0][2], k[1][2]
-    w2c_t = torch.tensor(np.asarray(w2c)).to(device).float()
-    inv = torch.inverse(w2c_t.cpu()).to(device)
-    cam_center = inv[:3, 3].clone() if true_campos else inv[3, :3].clone()
-    w2c_b = w2c_t.unsqueeze(0).transpose(1, 2)
-    opengl_proj = torch.tensor([[2 * fx / w, 0.0, -(w - 2 * cx) / w, 0.0],
-                                [0.0, 2 * fy / h, -(h - 2 * cy) / h, 0.0],
-                                [0.0, 0.0, far / (far - near), -(far * near) / (far - near)],
-                                [0.0, 0.0, 1.0, 0.0]]).to(device).float().unsqueeze(0).transpose(1, 2)
-    full_proj = w2c_b.bmm(opengl_proj)
-    return GaussianRasterizationSettings(
-        image_height=h,
-        image_width=w,
-        tanfovx=w / (2 * fx),
-        tanfovy=h / (2 * fy),
-        bg=torch.tensor([0, 0, 0], dtype=torch.float32, device=device),
-        scale_modifier=1.0,
-        viewmatrix=w2c_b,
-        projmatrix=full_proj,
-        sh_degree=0,
-        campos=cam_center,
-        prefiltered=False,
-        debug=False,
-    )
-
-
-def params2rendervar(params):
-    """Mirror of helpers.py:91-100: optimiser Parameters -> rasterizer kwargs."""
-    return {
-        'means3D': params['means3D'],
-        'colors_precomp': params['rgb_colors'],
-        'rotations': torch.nn.functional.normalize(params['unnorm_rotations']),
-        'opacities': torch.sigmoid(params['logit_opacities']),
-        'scales': torch.exp(params['log_scales']),
-        'means2D': torch.zeros_like(params['means3D'], requires_grad=True) + 0,
-    }
 
 
 class _Activate(torch.autograd.Function):
@@ -118,16 +67,4 @@ def params2rendervar_fused(params):
         'opacities': op,
         'scales': sc,
         'means2D': torch.zeros_like(params['means3D'], requires_grad=True) + 0,
-    }
-
-
-def params2rendervar_dense(params):
-    """Mirror of helpers.py:102-112 without the per-iteration device->host->device round trip of :109."""
-    return {
-        'means3D': params['dense_means3D'],
-        'colors_precomp': params['dense_rgb_colors'],
-        'rotations': torch.nn.functional.normalize(params['dense_unnorm_rotations']),
-        'opacities': torch.sigmoid(params['dense_logit_opacities']),
-        'scales': torch.exp(params['dense_log_scales']),
-        'means2D': torch.zeros_like(params['dense_means3D'], requires_grad=True) + 0,
     }

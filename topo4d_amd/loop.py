@@ -20,7 +20,7 @@ from typing import Callable, List, Optional
 import torch
 
 from . import loss as t4d_loss
-from .boundary import params2rendervar, params2rendervar_fused
+from .boundary import params2rendervar_fused
 from .rasterizer import GaussianRasterizer
 
 
@@ -36,10 +36,11 @@ def get_batch(todo_dataset: list, dataset: list, rng: Random, idx: Optional[int]
 
 
 def photometric_iteration(params, curr_data, fused_loss: bool = True, extra_loss: Optional[Callable] = None,
-                          fused_activations: bool = True):
-    """One forward of get_loss's photometric branch (train.py:303-328, use_mask False); returns (loss, radius)."""
-    on_gpu = params['means3D'].is_cuda
-    rendervar = params2rendervar_fused(params) if (fused_activations and on_gpu) else params2rendervar(params)
+                          params2rendervar: Optional[Callable] = None):
+    """One forward of get_loss's photometric branch (train.py:303-328, use_mask False); returns (loss, radius, rendervar).
+    `params2rendervar`: the function that turns the optimiser's parameters into rasterizer kwargs - Topo4D's own
+    helpers.params2rendervar (helpers.py:91-100) may be passed; the default is its fused equivalent (GPU only)."""
+    rendervar = (params2rendervar or params2rendervar_fused)(params)
     rendervar['means2D'].retain_grad()
     im, radius, _, _ = GaussianRasterizer(raster_settings=curr_data['cam'])(**rendervar)
     cid = curr_data['id']
