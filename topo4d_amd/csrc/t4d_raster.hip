@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             uint2 pk = *reinterpret_cast<const uint2 *>(list);
             T4D_STAMP(10 + 8 * (nb - 1 - bi));
 #ifdef T4D_TIMING
-            if (blockIdx.x == 0 && tid == 0) g_timing[13 + 8 * (nb - 1 - bi)] = nsteps;
+            if (blockIdx.x == 0 && tid == 0 && 13 + 8 * (nb - 1 - bi) < 512) g_timing[13 + 8 * (nb - 1 - bi)] = nsteps;
 #endif
             for (int k = 0; k < nsteps; k += 4) {
                 const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
