@@ -39,7 +39,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 ACHIEVABLE_HBM_GBS = 6290.0
-N_SIMD = 1024                  # 256 CUs x 4 SIMD-32
 
 
 def algorithmic_bytes(P, R, HW, S=0):
