@@ -20,13 +20,16 @@
 // Kernels (DESIGN.md has the bytes/roofline of each):
 //   k_preprocess      A.1  per (view,Gaussian): cull, project, cov3D, EWA cov2D, conic, radius, tile rect, SH colour;
 //                          + per-tile counts and pair ranks + pair-slot allocation (one returning atomic per workgroup)
-//   k_scan_tiles      A.2  per view: exclusive scan of tile counts -> tile offsets, overflow status, length buckets
+//   k_tile_chunk_sums, k_scan_tiles  A.2  per (view, 1024-tile chunk): exclusive scan of tile counts -> tile offsets, overflow
+//                          status, longest list, length buckets (the first kernel only when a view has more than one chunk)
 //   k_scatter         A.2  per (view,Gaussian): key -> tile_off + rank (no atomics); tail blocks build the work items
 //   k_sort_tiles      A.2  per work item: sort the bin by (depth bits, index): runs of 64 sorted in registers, merged by
-//                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS; beyond: LDS-sorted chunks merged
-//                          level by level in global memory)
+//                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS)
+//   k_sort_long       A.2  bins beyond 2048 keys (dense passes): a CU each - 1024 threads, 128 KiB of LDS for up to 16,384 keys,
+//                          longer ones chunk-sorted and merged in global memory
 //   k_render_fwd      A.3  per work item: 256 threads = 4 wave64 = 16 DPP rows, one 4x4 sub-block each; front-to-back blend
 //   k_render_bwd      A.4  per work item: back-to-front replay, row-local reduction, one record per pair
+//                          (both render kernels exist in a throughput and a latency build: see k_render_fwd)
 //   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D/SH chain rule
 //   k_view_dot_*, k_mark_visible: small utilities of the ABI
 #include <hip/hip_runtime.h>
