@@ -174,7 +174,6 @@ class Workload:
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
 
     def step(self, i):
-        from topo4d_amd.rasterizer import view_dot
         rv = self.rv_frames[i % len(self.rv_frames)]
         g = []
         S, world, dev = self.S, self.world, self.dev
@@ -193,9 +192,9 @@ class Workload:
                 b = self.batches[k]
                 color, radii, depth, alpha = b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
                                                        rv.get("colors_precomp"), rv.get("shs"))
-                g.append(b.backward(self.dcs[k]))
-                # per-view scalar loss term <colour, dL/dcolour>, one fused pass
-                view_dot(color, self.dcs[k], out=losses[self.bounds[k]:self.bounds[k + 1]])
+                # per-view scalar loss term <colour, dL/dcolour>: the backward's replay ends holding exactly this inner
+                # product per pixel, so it comes out of t4d_rasterize_backward (cotangent_dot), not out of a second pass
+                g.append(b.backward(self.dcs[k], cotangent_dot=losses[self.bounds[k]:self.bounds[k + 1]]))
         if S > 1:
             for st in self.streams:
                 main.wait_stream(st)

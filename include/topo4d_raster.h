@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define T4D_ABI_VERSION 1
+#define T4D_ABI_VERSION 2
 #define T4D_VIEW_FLOATS 40
 #define T4D_GRAD_PAIR_FLOATS 10   /* per (Gaussian,tile) partial-gradient record in the backward scratch */
 
@@ -122,6 +122,10 @@ typedef struct T4DBackwardIO {
     float *dL_dcov3D;             /* [V,P,6]   or NULL (required when cov3D_precomp) */
     void  *scratch;               /* t4d_backward_scratch_bytes() */
     size_t scratch_bytes;
+    float *cotangent_dot;         /* [V] or NULL.  out[v] = <color, dL_dcolor> + <depth, dL_ddepth> + <alpha, dL_dalpha> of view v:
+                                   * the replay's suffix sum IS this inner product when it reaches the eye, so the backward
+                                   * emits it for one reduction per tile instead of a second pass over both images
+                                   * (deterministic; agrees with the sum over the forward's outputs to fp32 rounding) */
 } T4DBackwardIO;
 
 uint32_t    t4d_abi_version(void);

@@ -336,3 +336,60 @@ def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
             np.testing.assert_array_equal(mine, os_["point_list"][os_["ranges"][t, 0]: os_["ranges"][t, 1]])
         check_outputs(hip, r.color, r.depth, r.alpha, v)
         check_grads(hg, g, v)
+
+
+def test_debug_flag_of_the_settings_tuple(render_build):
+    """`debug=True` (reference setup_camera passes False; upstream's flag dumps a snapshot on failure) maps to
+    T4D_FLAG_DEBUG_SYNC: synchronise and check after every kernel.  Same kernels, so results are bit-equal, forward and
+    backward, through the drop-in class."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    H, W = 120, 90
+    rv, cams = util.make_scene(24, 40, H, W, 1, opacity="B", seed=61)
+    cam = util.to_device(cams, "cuda")[0]
+    res = []
+    for debug in (False, True):
+        leaves = {k: v.cuda().requires_grad_(True) for k, v in rv.items()}
+        leaves["means2D"] = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        color, radii, depth, alpha = GaussianRasterizer(raster_settings=cam._replace(debug=debug))(**leaves)
+        (color.square().sum() + depth.sum() + 0.5 * alpha.sum()).backward()
+        res.append([t.detach().cpu().numpy() for t in (color, radii, depth, alpha)]
+                   + [leaves[k].grad.cpu().numpy() for k in sorted(leaves)])
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("with_depth_alpha", [False, True])
+@pytest.mark.parametrize("bg", [None, (0.3, 0.6, 0.1)])
+def test_cotangent_dot_from_the_backward(with_depth_alpha, bg, render_build):
+    """T4DBackwardIO.cotangent_dot: <color, dL_dcolor> (+ <depth, dL_ddepth> + <alpha, dL_dalpha>) per view, emitted by the
+    replay (its suffix sum at the eye) and by the empty tiles (background at T = 1).  Checked against the float64 inner
+    product of the forward's own outputs; ragged image (100 x 75: partial tiles), with and without a background, and the
+    gradients must not depend on whether the dot was asked for."""
+    from topo4d_amd import ViewBatch, pack_views
+    from scaffold import scene
+    H, W, V = 100, 75, 3
+    rv, cams = util.make_scene(24, 40, H, W, V, opacity="B", seed=71, bg=bg)
+    dc, dd, da = scene.output_cotangents(V, H, W, seed=72, depth_alpha=True)
+    if not with_depth_alpha:
+        dd = da = None
+    dev = torch.device("cuda")
+    batch = ViewBatch(pack_views(util.to_device(cams, dev), dev), H, W, 1.0, 0)
+    d = lambda k: rv[k].to(dev)
+    color, radii, depth, alpha = batch.forward(d("means3D"), d("opacities"), d("scales"), d("rotations"), d("colors_precomp"))
+    cot = [t if t is None else t.to(dev) for t in (dc, dd, da)]
+    dot = torch.full((V,), float("nan"), device=dev)
+    g_with = batch.backward(*cot, cotangent_dot=dot)
+    g_without = batch.backward(*cot)
+    for k in g_with:
+        if g_with[k] is not None:
+            assert torch.equal(g_with[k], g_without[k]), k
+    want = (color.double() * cot[0].double()).sum(dim=(1, 2, 3))
+    scale = (color.double() * cot[0].double()).abs().sum(dim=(1, 2, 3))
+    if with_depth_alpha:
+        want = want + (depth.double() * cot[1].double()).sum(dim=(1, 2, 3)) + (alpha.double() * cot[2].double()).sum(dim=(1, 2, 3))
+        scale = scale + (depth.double() * cot[1].double()).abs().sum(dim=(1, 2, 3)) + (alpha.double() * cot[2].double()).abs().sum(dim=(1, 2, 3))
+    err = (dot.double() - want).abs()
+    assert torch.all(err <= 2e-6 * scale), (dot, want, scale)
+    dot2 = torch.empty_like(dot)
+    batch.backward(*cot, cotangent_dot=dot2)
+    assert torch.equal(dot, dot2)                                   # fixed summation order

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # is still no fallback - a path that does not load raises.
 LIB_PATH = os.environ.get("T4D_LIB") or os.path.join(HERE, "csrc", "libtopo4d_raster.so")
 
-T4D_ABI_VERSION = 1
+T4D_ABI_VERSION = 2
 T4D_VIEW_FLOATS = 40
 T4D_GRAD_PAIR_FLOATS = 10
 
@@ -57,7 +57,7 @@ class T4DBackwardIO(C.Structure):
         "radii", "state")] + [("state_bytes", C.c_size_t)] + [(n, C.c_void_p) for n in (
             "dL_dcolor", "dL_ddepth", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dshs",
             "dL_dopacities", "dL_dscales", "dL_drotations", "dL_dcov3D", "scratch")] + [
-                ("scratch_bytes", C.c_size_t)]
+                ("scratch_bytes", C.c_size_t), ("cotangent_dot", C.c_void_p)]
 
 
 class T4DKernelTime(C.Structure):

@@ -162,6 +162,9 @@ struct KP {
     const float *dL_dcolor, *dL_ddepth, *dL_dalpha;
     float *grad_pair;
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dshs, *dL_dopacities, *dL_dscales, *dL_drotations, *dL_dcov3D;
+    float *tile_dot;         // [V,T,4] per-wave <outputs, cotangents> of every tile (scratch) or nullptr when the caller did not ask
+    float *cotangent_dot;    // [V]
+    uint32_t tile_blocks;    // k_render_bwd: workgroups that walk the tile list; the ones behind them do the empty tiles' dots
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1241,6 +1244,7 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #endif
 #define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_BWD_WAVES, LAT ? 2 : T4D_BWD_WAVES)))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
+constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the empty-tile share of cotangent_dot
 #ifdef T4D_TIMING      // experiment builds only (tools/ab_build.sh timing -DT4D_TIMING): s_memtime stamps of workgroup 0's phases
 __device__ unsigned long long g_timing[512];
 #define T4D_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 512) g_timing[(i)] = __builtin_readcyclecounter(); } while (0)
@@ -1281,8 +1285,35 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #pragma unroll
         for (int k = 0; k < kEnt / 8; k++) reinterpret_cast<float2 *>(s_rec + kNull * kEnt)[k] = make_float2(0.f, 0.f);
     }
+    if (blockIdx.x >= kp.tile_blocks) {
+        // Spare workgroups behind the tile workgroups, launched only when the caller asked for <outputs, cotangents>: the EMPTY
+        // tiles' share.  An empty tile shows the background at T = 1, so on black (Topo4D: helpers.py setup_camera, bg = 0)
+        // there is nothing to add and the workgroup leaves at once; otherwise it sums bg . dL/dC over its kEmptySpan tiles.
+        const uint32_t spans = (uint32_t)(kp.T + kEmptySpan - 1) / kEmptySpan;
+        const uint32_t j = blockIdx.x - kp.tile_blocks;
+        const int v = (int)(j / spans), t0 = (int)(j % spans) * kEmptySpan;
+        const float *vb = kp.views + (size_t)v * T4D_VIEW_FLOATS + 35;
+        const float b0 = vb[0], b1 = vb[1], b2 = vb[2];
+        if (b0 == 0.f && b1 == 0.f && b2 == 0.f) return;
+        const size_t HWe = (size_t)kp.H * kp.W;
+        const float *dc = kp.dL_dcolor + (size_t)v * 3 * HWe;
+        for (int t = t0; t < min(t0 + kEmptySpan, kp.T); t++) {
+            if (kp.tile_count[(size_t)v * kp.T + t] != 0u) continue;           // workgroup-uniform
+            const int ty = t / kp.gx, tx = t - ty * kp.gx;
+            int ex, ey;
+            tile_pixel(tid, tx, ty, ex, ey);
+            float d = 0.f;
+            if (ex < kp.W && ey < kp.H) {
+                const size_t pe = (size_t)ey * kp.W + ex;
+                d = fmaf(b0, dc[pe], fmaf(b1, dc[HWe + pe], b2 * dc[2 * HWe + pe]));
+            }
+            d = wave_sum_to_lane63(d);
+            if (lane == 63) kp.tile_dot[((size_t)v * kp.T + t) * 4 + wave] = d;
+        }
+        return;
+    }
     for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
-    for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {
+    for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += kp.tile_blocks) {
     const uint4 it = kp.items[item];
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
@@ -1548,6 +1579,13 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         }
         __syncthreads();
     }
+    if (kp.tile_dot) {
+        // The suffix recursion has reached the eye: acc = sum_i T_i alpha_i q_i = <colour - T_final bg, dL/dC> (+ <depth, dL/dD> +
+        // <alpha, dL/dA>), so acc + tf_bg is this pixel's <outputs, cotangents> - the per-view sum costs one reduction per tile.
+        // One float per wave, no barrier: a workgroup's lifetime is what this launch is made of.
+        const float d = wave_sum_to_lane63(acc + tf_bg);
+        if (lane == 63) kp.tile_dot[((size_t)v * kp.T + t_) * 4 + wave] = d;
+    }
     T4D_STAMP(4);
 #ifdef T4D_TIMING
     if (blockIdx.x == 0 && tid == 0) g_timing[6] = wall_clock64();
@@ -1562,6 +1600,25 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
 {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int v = blockIdx.y;
+    if (kp.tile_dot && blockIdx.x == gridDim.x - 1) {
+        // one spare workgroup per view: the view's <outputs, cotangents> = sum of its tiles' dots, in a fixed order
+        __shared__ float s_w[4];
+        const float4 *td = reinterpret_cast<const float4 *>(kp.tile_dot) + (size_t)v * kp.T;      // one float per wave of the tile
+        const float *vb = kp.views + (size_t)v * T4D_VIEW_FLOATS + 35;
+        const bool black = vb[0] == 0.f && vb[1] == 0.f && vb[2] == 0.f;        // then nobody wrote the empty tiles' entries
+        const uint32_t *tc = kp.tile_count + (size_t)v * kp.T;
+        float a = 0.f;
+        for (int t = threadIdx.x; t < kp.T; t += kBlock) {
+            if (tc[t] == 0u && black) continue;
+            const float4 d4 = td[t];
+            a += (d4.x + d4.y) + (d4.z + d4.w);
+        }
+        a = wave_sum_to_lane63(a);
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) kp.cotangent_dot[v] = kp.status->overflow != 0u ? 0.f : (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        return;
+    }
     if (g >= kp.P) return;
     const size_t vg = (size_t)v * kp.P + g;
     const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
@@ -1973,10 +2030,13 @@ T4D_EXPORT size_t t4d_state_bytes(const T4DProblem *prob)
     return make_layout(*prob).total;
 }
 
+size_t grad_pair_bytes(const T4DProblem &p) { return align_up((size_t)p.n_views * (size_t)p.pair_capacity * kGP * sizeof(float)); }
+
 T4D_EXPORT size_t t4d_backward_scratch_bytes(const T4DProblem *prob)
 {
     if (check_problem(prob) != T4D_OK) return 0;
-    return align_up((size_t)prob->n_views * (size_t)prob->pair_capacity * kGP * sizeof(float));
+    const size_t n_tiles = (size_t)((prob->W + T4D_TILE_X - 1) / T4D_TILE_X) * ((prob->H + T4D_TILE_Y - 1) / T4D_TILE_Y);
+    return grad_pair_bytes(*prob) + align_up((size_t)prob->n_views * n_tiles * 4 * sizeof(float));   // pair records | per-wave tile dots
 }
 
 T4D_EXPORT int t4d_debug_state_layout(const T4DProblem *prob, int has_sh, uint64_t *offsets, int n)
@@ -2103,23 +2163,31 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     kp.radii = const_cast<int32_t *>(io->radii);
     kp.dL_dcolor = io->dL_dcolor; kp.dL_ddepth = io->dL_ddepth; kp.dL_dalpha = io->dL_dalpha;
     kp.grad_pair = (float *)io->scratch;
+    if (io->cotangent_dot) {
+        kp.tile_dot = (float *)((char *)io->scratch + grad_pair_bytes(p));
+        kp.cotangent_dot = io->cotangent_dot;
+    }
     kp.dL_dmeans3D = io->dL_dmeans3D; kp.dL_dmeans2D = io->dL_dmeans2D; kp.dL_dcolors = io->dL_dcolors;
     kp.dL_dshs = io->dL_dshs; kp.dL_dopacities = io->dL_dopacities; kp.dL_dscales = io->dL_dscales;
     kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
 
     { ProfScope ps_(stream, K_RENDER_BWD);
     const bool da = kp.dL_ddepth || kp.dL_dalpha;
-    if (latency_launch(kp.T * p.n_views)) {
-        if (da) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_bwd<false, true>), dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
+    const bool lat = latency_launch(kp.T * p.n_views);
+    kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 4, 2));
+    const uint32_t grid = kp.tile_blocks + (kp.tile_dot ? (uint32_t)p.n_views * ((kp.T + kEmptySpan - 1) / kEmptySpan) : 0u);
+    if (lat) {
+        if (da) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_bwd<false, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
     } else {
-        if (da) hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_bwd<false, false>), dim3(tile_grid(kp.T * p.n_views, 4, 2)), dim3(kBlock), 0, stream, kp);
+        if (da) hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(grid), dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_bwd<false, false>), dim3(grid), dim3(kBlock), 0, stream, kp);
     }
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + kBlock - 1) / kBlock, p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + kBlock - 1) / kBlock + (kp.tile_dot ? 1 : 0), p.n_views), dim3(kBlock), 0,
+                       stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;

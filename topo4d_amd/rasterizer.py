@@ -379,9 +379,10 @@ class ViewBatch:
         return color, radii, depth, alpha
 
     # -- backward --------------------------------------------------------------------------------------------
-    def backward(self, dL_dcolor, dL_ddepth=None, dL_dalpha=None):
+    def backward(self, dL_dcolor, dL_ddepth=None, dL_dalpha=None, cotangent_dot=None):
         """Per-view gradients: dict of [V,P,...] tensors (means3D, means2D, colors_precomp|shs, opacities,
-        scales+rotations|cov3D_precomp)."""
+        scales+rotations|cov3D_precomp).  `cotangent_dot`: optional fp32 [V] tensor that receives
+        <color, dL_dcolor> + <depth, dL_ddepth> + <alpha, dL_dalpha> per view (a by-product of the replay)."""
         if self.state is None:
             raise RuntimeError("backward() before forward()")
         dev = self.device
@@ -393,6 +394,9 @@ class ViewBatch:
             raise ValueError("dL_dcolor must be [V,3,H,W]")
         dL_ddepth = _f32c(dL_ddepth, "dL_ddepth", dev)
         dL_dalpha = _f32c(dL_dalpha, "dL_dalpha", dev)
+        if cotangent_dot is not None and (cotangent_dot.dtype != torch.float32 or cotangent_dot.device != dL_dcolor.device
+                                          or cotangent_dot.numel() != V or not cotangent_dot.is_contiguous()):
+            raise ValueError("cotangent_dot must be a contiguous fp32 [V] tensor on the rasterizer's device")
         # separate allocations on purpose: autograd's AccumulateGrad only adopts a gradient without copying it when the
         # tensor owns its storage (carving them out of one buffer cost six clone kernels per backward)
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -410,7 +414,7 @@ class ViewBatch:
                            _ptr(self.state), self.state.numel(), _ptr(dL_dcolor), _ptr(dL_ddepth), _ptr(dL_dalpha),
                            _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["colors_precomp"]), _ptr(g["shs"]),
                            _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]),
-                           _ptr(scratch), sbytes)
+                           _ptr(scratch), sbytes, _ptr(cotangent_dot))
         rc = self.lib.t4d_rasterize_backward(C.byref(prob), C.byref(io), self._stream())
         if rc != T4D_OK:
             raise RuntimeError(f"t4d_rasterize_backward failed (code {rc}): {_lib.last_error()}")
