@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 // A.5 per-Gaussian backward: gather pair records, then the chain rule down to the inputs
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
+__device__ __forceinline__ void preprocess_bwd(const KP &kp, const bool SH)
 {
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int v = blockIdx.y;
@@ -1631,7 +1631,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
     float gm[3] = { 0.f, 0.f, 0.f }, g2x = 0.f, g2y = 0.f, gop = 0.f;
     float grgb[3] = { 0.f, 0.f, 0.f }, gsc[3] = { 0.f, 0.f, 0.f }, gq[4] = { 0.f, 0.f, 0.f, 0.f };
     float gcov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    const int K = kp.shs ? (kp.deg + 1) * (kp.deg + 1) : 0;
+    const int K = SH ? (kp.deg + 1) * (kp.deg + 1) : 0;
 
     if (radius > 0) {
         // ---- gather the partial gradients of this Gaussian's tiles ----
@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
         gm[0] += view[2] * gdep; gm[1] += view[6] * gdep; gm[2] += view[10] * gdep;
 
         // colour
-        if (kp.shs) {
+        if (SH) {
             const float d0[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
             const float len = sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
             const float d[3] = { d0[0] / len, d0[1] / len, d0[2] / len };
@@ -1809,7 +1809,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
             gq[2] = 2.f * x * (D[1] + D[3]) + 2.f * r * (D[2] - D[6]) + 2.f * z * (D[5] + D[7]) - 4.f * y * (D[0] + D[8]);
             gq[3] = 2.f * r * (D[3] - D[1]) + 2.f * x * (D[2] + D[6]) + 2.f * y * (D[5] + D[7]) - 4.f * z * (D[0] + D[4]);
         }
-    } else if (kp.shs) {
+    } else if (SH) {
         float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
         if ((kp.M & 3) == 0) {
             float4 *gsh4 = reinterpret_cast<float4 *>(gsh);
@@ -1831,6 +1831,18 @@ __global__ __launch_bounds__(kBlock) void k_preprocess_bwd(const KP kp)
         reinterpret_cast<float4 *>(kp.dL_drotations)[vg] = make_float4(gq[0], gq[1], gq[2], gq[3]);
     }
 }
+
+// Two entry points: without the SH rows (Topo4D's precomputed RGB) the body needs 76 registers instead of 142 and runs at six
+// waves per SIMD instead of three.  (With SH as a compile-time `true` the allocator lands at 181 registers = two waves: the SH
+// entry point keeps the run-time test.)
+#ifndef T4D_PBWD_WAVES
+#define T4D_PBWD_WAVES 6
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T4D_PBWD_WAVES, T4D_PBWD_WAVES))) void k_preprocess_bwd(const KP kp)
+{
+    preprocess_bwd(kp, false);
+}
+__global__ __launch_bounds__(kBlock) void k_preprocess_bwd_sh(const KP kp) { preprocess_bwd(kp, kp.shs != nullptr); }
 
 // ---------------------------------------------------------------------------------------------------------
 // per-view scalar <a, b> (e.g. the loss term sum(colour * dL/dcolour) each rank contributes to the loss gather):
@@ -2186,8 +2198,9 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((p.P + kBlock - 1) / kBlock + (kp.tile_dot ? 1 : 0), p.n_views), dim3(kBlock), 0,
-                       stream, kp);
+    const dim3 pgrid((p.P + kBlock - 1) / kBlock + (kp.tile_dot ? 1 : 0), p.n_views);
+    if (kp.shs) hipLaunchKernelGGL(k_preprocess_bwd_sh, pgrid, dim3(kBlock), 0, stream, kp);
+    else hipLaunchKernelGGL(k_preprocess_bwd, pgrid, dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;
