@@ -149,8 +149,8 @@ int t4d_fetch_status(const T4DProblem *prob, const void *state, T4DStatus *out, 
 /* present[i] = 1 iff Gaussian i passes the near-plane test of view record `view` (upstream markVisible). */
 int t4d_mark_visible(int32_t P, const float *means3D, const float *view, uint8_t *present, void *hip_stream);
 
-/* out[v] = sum_i a[v][i] * b[v][i] for v < n_views (one fused pass, deterministic).  The multi-GPU driver uses it
- * for the per-view scalar loss terms that are all-gathered over RCCL (sum(colour * dL/dcolour) in bench.py). */
+/* out[v] = sum_i a[v][i] * b[v][i] for v < n_views (one fused pass, deterministic): per-view scalars for a multi-GPU loss
+ * gather.  (For sum(colour * dL/dcolour) itself, T4DBackwardIO.cotangent_dot is free; bench.py uses that.) */
 size_t t4d_view_dot_scratch_bytes(int32_t n_views);
 int t4d_view_dot(int32_t n_views, int64_t n_per_view, const float *a, const float *b, float *out, void *scratch,
                  void *hip_stream);
