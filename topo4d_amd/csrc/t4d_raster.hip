@@ -1168,45 +1168,51 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 //   levels xor2, xor1 (quad_perm): plain butterflies on r1, r3, r5
 // On return, in lane i = (b3 b2 b1 b0) of a row:  r1 = sum of value 2*b2 + b3,  r3 = sum of value 4 + 2*b2 + b3,
 // r5 = sum of value 8 + b3.
+// Operands: values 2 and 5 are read-only inputs whose sums go to fresh registers (o2, o5): r[1], r[2] (and r[3], r[5]) are the
+// halves of ONE packed-multiply result, and tying both halves of a register pair to in/out operands costs a v_mov each.
 template <bool NINE>          // NINE: r[9] is known to be zero (no depth cotangent): its banked add is skipped
 __device__ __forceinline__ void reduce10_row(float (&r)[10])
 {
+    float o2, o5;
 #define T4D_RED_HEAD                                                                                  \
         "s_nop 1\n\t"                                                                                 \
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
-        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
-        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                           \
-        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                           \
-        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                           \
-        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                           \
-        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r0], %[r0], %[r0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                  \
+        "v_add_f32_dpp %[o2], %[r2], %[r2] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                  \
+        "v_add_f32_dpp %[r4], %[r4], %[r4] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                  \
+        "v_add_f32_dpp %[r6], %[r6], %[r6] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                  \
+        "v_add_f32_dpp %[r8], %[r8], %[r8] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                  \
+        "v_add_f32_dpp %[r0], %[r1], %[r1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                  \
+        "v_add_f32_dpp %[o2], %[r3], %[r3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                  \
+        "v_add_f32_dpp %[r4], %[r5], %[r5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                  \
+        "v_add_f32_dpp %[r6], %[r7], %[r7] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
 #define T4D_RED_TAIL                                                                                  \
-        "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
-        "v_add_f32_dpp %3, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
-        "v_add_f32_dpp %5, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                           \
-        "v_add_f32_dpp %1, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
-        "v_add_f32_dpp %3, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
-        "v_add_f32_dpp %5, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                           \
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                 \
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                 \
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                 \
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        "v_add_f32_dpp %[r1], %[r0], %[r0] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                  \
+        "v_add_f32_dpp %[r3], %[r4], %[r4] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                  \
+        "v_add_f32_dpp %[o5], %[r8], %[r8] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                  \
+        "v_add_f32_dpp %[r1], %[o2], %[o2] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                  \
+        "v_add_f32_dpp %[r3], %[r6], %[r6] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                  \
+        "v_add_f32_dpp %[o5], %[r8], %[r8] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                  \
+        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_add_f32_dpp %[o5], %[o5], %[o5] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_add_f32_dpp %[o5], %[o5], %[o5] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+#define T4D_RED_OUT [r0] "+v"(r[0]), [r1] "+v"(r[1]), [o2] "=&v"(o2), [r3] "+v"(r[3]), [r4] "+v"(r[4]), [o5] "=&v"(o5), \
+                    [r6] "+v"(r[6]), [r8] "+v"(r[8])
     if (NINE) {
-        // %8 then holds the xor8 sum of value 8 in BOTH halves of the row; only the b3 = 0 lane is used (row10_index)
-        asm(T4D_RED_HEAD T4D_RED_TAIL
-            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]));
+        // r8 then holds the xor8 sum of value 8 in BOTH halves of the row; only the b3 = 0 lane is used (row10_index)
+        asm(T4D_RED_HEAD T4D_RED_TAIL : T4D_RED_OUT : [r2] "v"(r[2]), [r5] "v"(r[5]), [r7] "v"(r[7]));
     } else {
         asm(T4D_RED_HEAD
-            "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %[r8], %[r9], %[r9] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             T4D_RED_TAIL
-            : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]));
+            : T4D_RED_OUT : [r2] "v"(r[2]), [r5] "v"(r[5]), [r7] "v"(r[7]), [r9] "v"(r[9]));
     }
+    r[5] = o5;
 #undef T4D_RED_HEAD
 #undef T4D_RED_TAIL
+#undef T4D_RED_OUT
 }
 
 // which of the ten sums lane i of a row keeps after reduce10_row (taken from r1 / r3 / r5 by (b1 b0)); -1 = none
@@ -1267,12 +1273,25 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     constexpr int kEnt = 40;
     static_assert(kGP == kAcc, "the slab entry and the scratch record hold the same ten sums");
     static_assert(kAcc * 4 == kEnt, "a slab entry and a staged record must have the same stride");
-    __shared__ __attribute__((aligned(8))) unsigned char s_rec[(kBwdBatch + 1) * kEnt];
-    __shared__ uint32_t s_pair[kBwdBatch];
-    __shared__ __attribute__((aligned(8))) float s_acc[kSlabs][kBwdBatch + 1][kAcc];   // + the null splat's (never read) row
-    __shared__ unsigned long long s_mask[16][kChunks];
-    __shared__ uint32_t s_wmax[4];
-    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
+    // One struct, so that the layout is ours: the staged records sit at LDS offset 0 and the replay's paired 8-byte reads reach
+    // them with immediate offsets (behind the slabs, at 20 KiB, every step paid a vector add for the address).
+    struct __attribute__((aligned(16))) Shared {
+        unsigned char rec[(kBwdBatch + 1) * kEnt];
+        float acc[kSlabs][kBwdBatch + 1][kAcc];                 // + the null splat's (never read) row
+        unsigned short list[4][4][kListStride];
+        unsigned long long mask[16][kChunks];
+        uint32_t pair[kBwdBatch];
+        uint32_t wmax[4];
+    };
+    static_assert(((kBwdBatch + 1) * kEnt) % 8 == 0 && (sizeof(float) * kSlabs * (kBwdBatch + 1) * kAcc) % 8 == 0 &&
+                  (sizeof(unsigned short) * 16 * kListStride) % 8 == 0, "8-byte members must stay 8-byte aligned");
+    __shared__ Shared sh;
+    auto &s_rec = sh.rec;
+    auto &s_pair = sh.pair;
+    auto &s_acc = sh.acc;
+    auto &s_mask = sh.mask;
+    auto &s_wmax = sh.wmax;
+    auto &s_list = sh.list;
     constexpr int kNull = kBwdBatch;
 
     const int tid = threadIdx.x;
