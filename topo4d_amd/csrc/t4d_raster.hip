@@ -956,7 +956,7 @@ __device__ __forceinline__ void eval_splat(const float4 q, const v2f d, float &p
 #pragma clang fp contract(off)
     const v2f qac = { q.x, q.y };
     const v2f m = qac * d;
-    p2 = fmaf(m.x, d.x, fmaf(m.y, d.y, (q.z * d.x) * d.y));
+    p2 = fmaf(fmaf(q.z, d.y, m.x), d.x, m.y * d.y);          // (A dx + B dy) dx + C dy^2: four instructions with the packed multiply
     G = __builtin_amdgcn_exp2f(p2);
     alpha = fminf(T4D_ALPHA_MAX, q.w * G);
 }
