@@ -1095,6 +1095,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         nsteps = 0;
 #endif
         uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
+        unsigned long long done_m = __ballot(done);
         for (int k = 0; k < nsteps; k += kU) {
             uint32_t e[kU];
 #pragma unroll
@@ -1103,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 e[4 * h] = pk.x & 0xffffu; e[4 * h + 1] = pk.x >> 16; e[4 * h + 2] = pk.y & 0xffffu; e[4 * h + 3] = pk.y >> 16;
             }
             float alpha[kU];
-            bool valid[kU];
+            unsigned long long valid[kU];                // lane predicates are kept as wave masks: see the blend below
             float4 cds[kU];
 #pragma unroll
             for (int u = 0; u < kU; u++) {               // independent evaluations: ILP hides LDS / exp latency
@@ -1111,7 +1112,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 if (LAT) cds[u] = *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);      // every LDS read of the group up front
                 float p2, G;
                 eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy - pix_f, p2, G, alpha[u]);
-                valid[u] = !(p2 > 0.0f) && !(alpha[u] < T4D_ALPHA_MIN);
+                valid[u] = __ballot(!(p2 > 0.0f)) & __ballot(!(alpha[u] < T4D_ALPHA_MIN));
             }
 #if T4D_ABL == 4
             if (alpha[0] + alpha[1] + alpha[2] + alpha[3] == 12345.f) C0 += 1.f;
@@ -1120,11 +1121,13 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             // (no "does any lane blend?" test: with four different splats in flight per step the answer is almost always yes)
 #pragma unroll
             for (int u = 0; u < kU; u++) {               // blending is sequential in list order
-                bool ok = valid[u] && !done;
+                // Predicates as 64-bit wave masks combined with scalar instructions: written with bools, the compiler evaluates
+                // "below" and "not below" as two vector compares (one instruction in 25 per step).
                 const float test_T = T * (1.f - alpha[u]);
-                const bool below = test_T < T4D_T_STOP;
-                done = done || (ok && below);
-                ok = ok && !below;
+                const unsigned long long below = __ballot(test_T < T4D_T_STOP);
+                const unsigned long long live = valid[u] & ~done_m;
+                done_m |= live & below;
+                const bool ok = __builtin_amdgcn_inverse_ballot_w64(live & ~below);
                 const float4 cd = LAT ? cds[u] : *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);
                 const float w = ok ? alpha[u] * T : 0.f;
                 C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
@@ -1133,8 +1136,9 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 T = ok ? test_T : T;
                 last_e = ok ? e[u] : last_e;
             }
-            if (__all(done)) break;
+            if (done_m == ~0ull) break;
         }
+        done = __builtin_amdgcn_inverse_ballot_w64(done_m);
         if (last_e != 0xffffffffu) last_contributor = b + ((last_e * 43691u) >> 21) + 1u;     // entry / 48 for entries < 2^17
     }
     if (inside) {
