@@ -820,12 +820,35 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 {
     __shared__ unsigned long long s_keys[kSortLdsCap];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t n_items = (uint32_t)(kp.V * kp.T);
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint4 it = kp.items[item];
+    // Work units.  The item list is ordered by length class (floor(log2 n), descending), and bucket_fill holds the size of every
+    // class: bins of 64 keys and more are one unit per workgroup; bins of 2..63 keys fit one register-sorted run, need neither LDS
+    // nor a barrier, and go FOUR to a unit, one per wave (a high-resolution pass has mostly such bins: config 4 averages 65 keys
+    // per non-empty tile, and three of the four waves of a one-bin workgroup did nothing).
+    constexpr int kClass63 = (kBuckets - 2) - 5, kClass1 = kBuckets - 2;       // classes of n in [32, 63] and of n == 1
+    uint32_t n_big = 0, n_small = 0;
+#pragma unroll
+    for (int k = 0; k < kBuckets - 1; k++) {
+        const uint32_t f = kp.bucket_fill[k];
+        if (k < kClass63) n_big += f;
+        else if (k < kClass1) n_small += f;
+    }
+    const uint32_t n_units = n_big + ((n_small + 3u) >> 2);
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        if (unit >= n_big) {
+            const uint32_t item = n_big + 4u * (unit - n_big) + (uint32_t)wave;     // wave-uniform
+            if (item < n_big + n_small) {
+                const uint4 it = kp.items[item];
+                const uint32_t n = it.z;
+                unsigned long long *keys = kp.keys + (size_t)(it.x >> 20) * kp.cap + it.y;
+                unsigned long long k0 = (uint32_t)lane < n ? keys[lane] : ~0ull;
+                wave_sort64(k0, lane);
+                if ((uint32_t)lane < n) keys[lane] = k0;
+            }
+            continue;
+        }
+        const uint4 it = kp.items[unit];
         const int v = (int)(it.x >> 20);
         const uint32_t off = it.y, n = it.z;
-        if (n < 2) break;                                          // items are ordered by length: nothing left
         unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
         if (n <= (uint32_t)kRankSortMax) {
             // Runs of 64 keys are sorted inside a wave's registers (no LDS, no barrier); a key's final position is its
