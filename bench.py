@@ -3,7 +3,7 @@
 bench.py — rasterizer forward+backward views/sec on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4] [--opacity A|B] [--scaling weak|strong]
-                    [--no-cpu-baseline] [--no-extras]
+                    [--frames-in-flight F] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,6 +11,10 @@ One "step" = one pass of the hot path over one batch: forward + backward of the 
 (BASELINE config 2: 24 x 512x512, P = 30,000 vertex-bound Gaussians, precomputed RGB) through the C ABI, with
 all inputs already resident in HBM and seeded dL/dcolor supplied.  One "view" = one
 (Settings, params) -> colour/depth/alpha -> per-view dL/dparams round trip.
+Frames are independent units, so F = 2 of them are in flight on two HIP streams (own state buffers each): the latency-bound
+binning kernels of one frame run beside the issue-bound render kernels of the other.  Every step is still executed in full, K
+steps are timed; `sequential` in the JSON line is the same run with F = 1, and the per-kernel figures of `roofline` are taken
+with F = 1 (a kernel alone on the chip).
 
 Multi-GPU (BASELINE config 3): the 64-frame sequence is sharded by frame — rank r renders frames r, r+N, ...
   --scaling weak   (default; what the driver runs): every rank times K steps, per-GPU work is fixed (24 views per step);
@@ -20,8 +24,8 @@ next step.
 
 The JSON line carries `roofline` (dominant kernel by HIP-event time, algorithmic bytes per launch, HBM traffic and the
 vector-ALU counters of the committed rocprofv3 passes), `cpu_baseline` (oracle/raster_oracle.c, OpenMP, bounded sample,
-min of 5), `scenario_b` (the same workload with unsaturated opacities) and `single_view` (the reference's own call shape:
-one camera per call, P = 8,280, 512x375) — see DESIGN.md §Measurement.
+min of 5), `scenario_b` (the same workload with unsaturated opacities), `single_view` (the reference's own call shape:
+one camera per call, P = 8,280, 512x375) and `sequential` — see DESIGN.md §Measurement.
 """
 from __future__ import annotations
 
@@ -131,9 +135,11 @@ def cpu_baseline(cfg, n_sample_views, reps):
 
 class Workload:
     """The timed thing: `step(i)` = forward + backward of this rank's frame i (all V views in one launch set) + the per-view
-    loss scalars + (N > 1) their asynchronous all_gather."""
+    loss scalars + (N > 1) their asynchronous all_gather.  Frames are independent units (SURVEY 8e shards them over GPUs for the
+    same reason): `in_flight` of them are in flight on as many HIP streams, each with its own state buffers, so that the
+    latency-bound binning kernels of one frame run beside the issue-bound render kernels of the other."""
 
-    def __init__(self, cfgname, opacity, dev, rank=0, world=1, n_streams=1, n_frames=64, resident=8):
+    def __init__(self, cfgname, opacity, dev, rank=0, world=1, in_flight=2, n_frames=64, resident=8):
         from scaffold import reference_boundary as boundary, scene
         from topo4d_amd import ViewBatch, dist as t4d_dist, pack_views
         self.t4d_dist = t4d_dist
@@ -148,7 +154,7 @@ class Workload:
             cams = [c._replace(sh_degree=cfg["sh_degree"]) for c in cams]
         views = pack_views(cams, dev)
         dc, _, _ = scene.output_cotangents(V, H, W, seed=0)
-        dc = dc.to(dev)
+        self.dc = dc.to(dev).contiguous()
         # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
         self.n_frames = n_frames
         my_frames = t4d_dist.shard_units(n_frames, rank, world)
@@ -161,51 +167,39 @@ class Workload:
                 rv["shs"] = params["shs"].to(dev)
                 rv.pop("colors_precomp")
             self.rv_frames.append(rv)
-        self.S = S = max(1, min(n_streams, V))
-        self.bounds = [(V * k) // S for k in range(S + 1)]
-        self.batches = [ViewBatch(views[self.bounds[k]:self.bounds[k + 1]].contiguous(), H, W, 1.0, cfg["sh_degree"] or 0)
-                        for k in range(S)]
-        self.dcs = [dc[self.bounds[k]:self.bounds[k + 1]].contiguous() for k in range(S)]
-        self.losses = torch.zeros(V, device=dev)
-        # multi-GPU: the loss all_gather of step i overlaps with step i+1 (double-buffered, waited on two steps later)
-        self.loss_bufs = [torch.zeros(V, device=dev), torch.zeros(V, device=dev)]
-        self.gath_bufs = [torch.zeros(V * world, device=dev), torch.zeros(V * world, device=dev)]
-        self.pending = [None, None]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
+        self.F = F = max(1, in_flight)
+        # one slot per frame in flight: its own state buffers (ViewBatch), stream, loss and gather buffers
+        self.batches = [ViewBatch(views.contiguous(), H, W, 1.0, cfg["sh_degree"] or 0) for _ in range(F)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [None]
+        # multi-GPU: the loss all_gather of a step overlaps with the following steps; a slot waits for its previous gather
+        # before it rewrites its buffers (F = 1: two buffer sets, the gather of step i is waited on at step i + 2)
+        self.sequential = False          # True: one frame after the other on the current stream (per-kernel event pass, comparison run)
+        self.n_bufs = nb = max(2, F)
+        self.loss_bufs = [torch.zeros(V, device=dev) for _ in range(nb)]
+        self.gath_bufs = [torch.zeros(V * world, device=dev) for _ in range(nb)]
+        self.pending = [None] * nb
 
     def step(self, i):
         rv = self.rv_frames[i % len(self.rv_frames)]
-        g = []
-        S, world, dev = self.S, self.world, self.dev
-        losses = self.losses
-        if world > 1:
-            if self.pending[i % 2] is not None:
-                self.pending[i % 2].wait()
-                self.pending[i % 2] = None
-            losses = self.loss_bufs[i % 2]
-        if S > 1:
-            main = torch.cuda.current_stream(dev)
-            for st in self.streams:
-                st.wait_stream(main)
-        for k in range(S):
-            with torch.cuda.stream(self.streams[k]) if S > 1 else contextlib.nullcontext():
-                b = self.batches[k]
-                color, radii, depth, alpha = b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"],
-                                                       rv.get("colors_precomp"), rv.get("shs"))
-                # per-view scalar loss term <colour, dL/dcolour>: the backward's replay ends holding exactly this inner
-                # product per pixel, so it comes out of t4d_rasterize_backward (cotangent_dot), not out of a second pass
-                g.append(b.backward(self.dcs[k], cotangent_dot=losses[self.bounds[k]:self.bounds[k + 1]]))
-        if S > 1:
-            for st in self.streams:
-                main.wait_stream(st)
-        if world > 1:
-            out, work = self.t4d_dist.gather_losses_async(losses, self.gath_bufs[i % 2])
-            self.pending[i % 2] = work
-            return out, g
-        return losses, g
+        slot, k = (0 if self.sequential else i % self.F), i % self.n_bufs
+        with torch.cuda.stream(self.streams[slot]) if self.F > 1 and not self.sequential else contextlib.nullcontext():
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+            losses = self.loss_bufs[k]
+            b = self.batches[slot]
+            b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv.get("colors_precomp"), rv.get("shs"))
+            # per-view scalar loss term <colour, dL/dcolour>: the backward's replay ends holding exactly this inner product per
+            # pixel, so it comes out of t4d_rasterize_backward (cotangent_dot), not out of a second pass over both images
+            g = b.backward(self.dc, cotangent_dot=losses)
+            if self.world > 1:
+                out, work = self.t4d_dist.gather_losses_async(losses, self.gath_bufs[k])
+                self.pending[k] = work
+                return out, [g]
+        return losses, [g]
 
     def drain(self):
-        for k in range(2):
+        for k in range(self.n_bufs):
             if self.pending[k] is not None:
                 self.pending[k].wait()
                 self.pending[k] = None
@@ -220,6 +214,7 @@ class Workload:
         topo4d_amd.set_sync_mode("lazy")
 
     def statuses(self):
+        """binning status of the last frame each slot rendered (every slot renders all V views of a frame)"""
         return [b.fetch_status() for b in self.batches]
 
 
@@ -252,17 +247,21 @@ def timed_run(wl, steps, warmup, prewarm_s, barrier, all_reduce_max):
 
 def kernel_profile(wl, steps):
     """Per-kernel durations with HIP events recorded on the launch stream inside the library (same steps again, so that the
-    timed region carries no event overhead).  Returns ({kernel: (total_ms, launches)}, wall seconds)."""
+    timed region carries no event overhead, and with ONE frame in flight, so that a kernel's duration is its own).  Returns
+    ({kernel: (total_ms, launches)}, wall seconds)."""
     from topo4d_amd import _lib
     torch.cuda.synchronize(wl.dev)
+    wl.sequential = True             # a kernel's own duration: one frame at a time, nothing else on the chip
     if wl.rank == 0:
         _lib.profile_begin()
     tp0 = time.perf_counter()
     for i in range(steps):
         wl.step(i)
+    wl.drain()
     torch.cuda.synchronize(wl.dev)
     tp = time.perf_counter() - tp0
     prof = _lib.profile_end() if wl.rank == 0 else {}
+    wl.sequential = False
     return prof, tp
 
 
@@ -328,8 +327,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the scenario-B and single-view side measurements")
     ap.add_argument("--cpu-sample-views", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("T4D_BENCH_STREAMS", "1")),
-                    help="split the views of a step over this many HIP streams (independent views overlap their kernel tails)")
+    ap.add_argument("--frames-in-flight", dest="in_flight", type=int, default=int(os.environ.get("T4D_BENCH_IN_FLIGHT", "2")),
+                    help="independent frames in flight on as many HIP streams (1 = one frame after the other on one stream)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 64 if args.scaling == "strong" else 50
@@ -364,7 +363,7 @@ def main():
 
     import topo4d_amd
 
-    wl = Workload(args.config, args.opacity, dev, rank, world, args.streams)
+    wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
     my_steps = args.steps // world if args.scaling == "strong" else args.steps
 
@@ -385,10 +384,17 @@ def main():
 
     wl.learn_capacity()
     dt, t_enqueue = timed_run(wl, my_steps, args.warmup, args.prewarm_s, barrier, all_reduce_max)
+    sequential = None
+    if wl.F > 1:                     # the same steps, one frame after the other on one stream: what the overlap is worth
+        wl.sequential = True
+        dts, _ = timed_run(wl, my_steps, args.warmup, 0.05, barrier, all_reduce_max)
+        wl.sequential = False
+        sequential = {"ms_per_step": round(1e3 * dts / my_steps, 4), "value": round(V * my_steps * world / dts, 2), "unit": "views/s",
+                      "note": "frames_in_flight = 1: the same steps one after the other on one stream"}
     sts = wl.statuses()
     if any(x.overflow for x in sts):
         raise SystemExit("pair arena overflowed during the timed region: result invalid")
-    total_pairs_all = sum(x.total_pairs for x in sts)
+    total_pairs_all = sts[0].total_pairs
     # T4D_BENCH_DUMP_LOSSES=k (tests): the gathered per-view loss vectors of this rank's first k steps go into the JSON line
     last_losses = None
     if os.environ.get("T4D_BENCH_DUMP_LOSSES"):
@@ -440,7 +446,7 @@ def main():
                 dtb, _ = timed_run(wb, my_steps, args.warmup, 0.1, lambda: torch.cuda.synchronize(dev), lambda x: x)
                 stb = wb.statuses()
                 scenario_b = {"value": round(V * my_steps / dtb, 2), "unit": "views/s", "ms_per_step": round(1e3 * dtb / my_steps, 4),
-                              "steps": my_steps, "pairs_per_view": int(sum(x.total_pairs for x in stb) / V),
+                              "steps": my_steps, "pairs_per_view": int(stb[0].total_pairs / V),
                               "overflow": bool(any(x.overflow for x in stb)),
                               "workload": "same as config.workload with opacity scenario B: uniform(0.05, 0.95)"}
                 del wb
@@ -473,8 +479,8 @@ def main():
                        "views_per_step_per_gpu": V, "frames": wl.n_frames, "steps_per_rank": my_steps,
                        "parallelism": f"frame-sharded x{world}",
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
-                       "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "hip_streams": wl.S},
-            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view,
+                       "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "frames_in_flight": wl.F},
+            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "sequential": sequential,
         }
         if last_losses is not None:
             out["gathered_losses_first_steps"] = last_losses

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 RAW=/tmp/prof_raw_$TAG
 rm -rf $RAW; mkdir -p $OUT $RAW
 cd /tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-extras"
+B="python $ROOT/bench.py --no-cpu-baseline --no-extras --frames-in-flight 1"     # kernels alone on the chip: per-kernel figures
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o t -- $B --steps 20 --warmup 3 "$@" > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $RAW/pmc1 -o p -- $B --steps 2 --warmup 1 "$@" > $OUT/bench_pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $RAW/pmc2 -o p -- $B --steps 2 --warmup 1 "$@" > $OUT/bench_pmc2.log 2>&1
