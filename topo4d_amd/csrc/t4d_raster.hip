@@ -1192,15 +1192,18 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 // needed inside; the leading s_nop covers inputs produced just before the block.
 //   level xor8 (row_ror:8):  r[2m] <- r[2m + b3] summed over the pair          (banks 2,3 = lanes with b3 set)
 //   level xor4 (row_shl/shr:4): r1 <- c_{b2}, r3 <- c_{2+b2}, r5 <- c_4        (banks 0,2 read lane+4; banks 1,3 lane-4)
-//   levels xor2, xor1 (quad_perm): plain butterflies on r1, r3, r5
-// On return, in lane i = (b3 b2 b1 b0) of a row:  r1 = sum of value 2*b2 + b3,  r3 = sum of value 4 + 2*b2 + b3,
-// r5 = sum of value 8 + b3.
+//   levels xor2, xor1 (quad_perm): no bank masks at this granularity (a bank is four consecutive lanes), so the transposing
+//   is done with selects on the constant lane masks b1 / b0: xor2 folds (r1, r3) into one register and r5 into itself, xor1
+//   folds those two into ONE - seven instructions, and the caller needs no selection (plain butterflies on the three
+//   registers plus the caller's two selects were eight).
+// Returns, in lane i = (b3 b2 b1 b0) of a row: the sum of value  2*b2 + b3  (b1 b0 = 00),  4 + 2*b2 + b3  (b1 b0 = 10),
+// 8 + b3  (b0 = 1; four lanes per half row hold it, row10_index picks b2 = b1 = 0).
 // Operands: values 2 and 5 are read-only inputs whose sums go to fresh registers (o2, o5): r[1], r[2] (and r[3], r[5]) are the
 // halves of ONE packed-multiply result, and tying both halves of a register pair to in/out operands costs a v_mov each.
 template <bool NINE>          // NINE: r[9] is known to be zero (no depth cotangent): its banked add is skipped
-__device__ __forceinline__ void reduce10_row(float (&r)[10])
+__device__ __forceinline__ float reduce10_row(float (&r)[10])
 {
-    float o2, o5;
+    float o2, o5, ta, tb;
 #define T4D_RED_HEAD                                                                                  \
         "s_nop 1\n\t"                                                                                 \
         "v_add_f32_dpp %[r0], %[r0], %[r0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                  \
@@ -1219,36 +1222,40 @@ __device__ __forceinline__ void reduce10_row(float (&r)[10])
         "v_add_f32_dpp %[r1], %[o2], %[o2] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                  \
         "v_add_f32_dpp %[r3], %[r6], %[r6] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                  \
         "v_add_f32_dpp %[o5], %[r8], %[r8] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"                  \
-        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
-        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_cndmask_b32_e64 %[tb], %[r3], %[r1], %[m1]\n\t"              /* b1 ? r1 : r3  (goes to the partner) */ \
+        "v_cndmask_b32_e64 %[ta], %[r1], %[r3], %[m1]\n\t"              /* b1 ? r3 : r1  (stays)               */ \
         "v_add_f32_dpp %[o5], %[o5], %[o5] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
-        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"        \
-        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"        \
-        "v_add_f32_dpp %[o5], %[o5], %[o5] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        "v_add_f32_dpp %[ta], %[tb], %[ta] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+        "v_cndmask_b32_e64 %[tb], %[o5], %[ta], %[m0]\n\t"              /* b0 ? x : y  (goes to the partner)   */ \
+        "v_cndmask_b32_e64 %[ta], %[ta], %[o5], %[m0]\n\t"              /* b0 ? y : x  (stays)                 */ \
+        "s_nop 0\n\t"                                                                                 \
+        "v_add_f32_dpp %[ta], %[tb], %[ta] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 #define T4D_RED_OUT [r0] "+v"(r[0]), [r1] "+v"(r[1]), [o2] "=&v"(o2), [r3] "+v"(r[3]), [r4] "+v"(r[4]), [o5] "=&v"(o5), \
-                    [r6] "+v"(r[6]), [r8] "+v"(r[8])
+                    [r6] "+v"(r[6]), [r8] "+v"(r[8]), [ta] "=&v"(ta), [tb] "=&v"(tb)
+#define T4D_RED_MASKS [m1] "s"(0xccccccccccccccccull), [m0] "s"(0xaaaaaaaaaaaaaaaaull)
     if (NINE) {
         // r8 then holds the xor8 sum of value 8 in BOTH halves of the row; only the b3 = 0 lane is used (row10_index)
-        asm(T4D_RED_HEAD T4D_RED_TAIL : T4D_RED_OUT : [r2] "v"(r[2]), [r5] "v"(r[5]), [r7] "v"(r[7]));
+        asm(T4D_RED_HEAD T4D_RED_TAIL : T4D_RED_OUT : [r2] "v"(r[2]), [r5] "v"(r[5]), [r7] "v"(r[7]), T4D_RED_MASKS);
     } else {
         asm(T4D_RED_HEAD
             "v_add_f32_dpp %[r8], %[r9], %[r9] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             T4D_RED_TAIL
-            : T4D_RED_OUT : [r2] "v"(r[2]), [r5] "v"(r[5]), [r7] "v"(r[7]), [r9] "v"(r[9]));
+            : T4D_RED_OUT : [r2] "v"(r[2]), [r5] "v"(r[5]), [r7] "v"(r[7]), [r9] "v"(r[9]), T4D_RED_MASKS);
     }
-    r[5] = o5;
+    return ta;
 #undef T4D_RED_HEAD
 #undef T4D_RED_TAIL
 #undef T4D_RED_OUT
+#undef T4D_RED_MASKS
 }
 
-// which of the ten sums lane i of a row keeps after reduce10_row (taken from r1 / r3 / r5 by (b1 b0)); -1 = none
+// which of the ten sums lane i of a row holds after reduce10_row; -1 = none (or a duplicate)
 __device__ __forceinline__ int row10_index(const int lane)
 {
     const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
-    if (!b1 && !b0) return 2 * b2 + b3;
-    if (!b1 && b0) return 4 + 2 * b2 + b3;
-    if (b1 && !b0 && !b2) return 8 + b3;
+    if (!b0 && !b1) return 2 * b2 + b3;
+    if (!b0 && b1) return 4 + 2 * b2 + b3;
+    if (b0 && !b1 && !b2) return 8 + b3;
     return -1;
 }
 
@@ -1326,7 +1333,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     // without a depth cotangent the ninth pair is not transposed (reduce10_row<true>): the lane that would hold sum 9 holds a
     // second copy of sum 8 and must stay out
     const int my_slot = (!DA && row10_index(lane & 15) == 9) ? -1 : row10_index(lane & 15);
-    const bool sel_mid = (lane & 3) == 1, sel_hi = (lane & 3) == 2;
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < kEnt / 8; k++) reinterpret_cast<float2 *>(s_rec + kNull * kEnt)[k] = make_float2(0.f, 0.f);
@@ -1578,8 +1584,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #if T4D_ABL == 1 || T4D_ABL == 2
                     if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + old == 12345.f) s_acc[wave][0][0] = r[0];
 #else
-                    reduce10_row<!DA>(r);
-                    const float tot = sel_hi ? r[5] : (sel_mid ? r[3] : r[1]);
+                    const float tot = reduce10_row<!DA>(r);
                     // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Idle
                     // rows add their zeros to the null splat's row, which nobody reads.
                     const bool add = my_slot >= 0;
