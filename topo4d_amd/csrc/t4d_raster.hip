@@ -153,6 +153,7 @@ struct KP {
     float *rgb;
     uint8_t *clamped;
     unsigned long long *keys, *sort_tmp;       // sort_tmp: ping-pong arena for bins longer than the LDS sort buffer
+    uint16_t *touch;                           // [V,cap] sub-block touch mask of every sorted pair: written by the forward's staging, read by the backward's (lives in the pair_rank arena, which is dead once k_scatter has run)
     float *final_T;
     uint32_t *n_contrib;
     // forward outputs
@@ -1061,6 +1062,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+    uint16_t *touch_out = kp.touch + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
     const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
@@ -1091,6 +1093,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                                                                    __uint_as_float((uint32_t)(key >> 32)));
                 touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
             }
+            touch_out[b + tid] = (uint16_t)touch;        // the backward stages the same splats: it reads the mask back
         }
         if (wave < kChunks) {
 #pragma unroll
@@ -1376,6 +1379,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #endif
     if (n == 0) break;                                             // ordered by length: only empty tiles remain
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+    const uint16_t *touch_in = kp.touch + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
     const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
@@ -1447,7 +1451,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                 rec[2] = make_float2(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1]);
                 rec[3] = make_float2(rgb[3 * (size_t)g + 2], __uint_as_float((uint32_t)(key >> 32)));
                 rec[4] = p;
-                touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
+                touch = touch_in[lo + tid];              // = subblock_touch_mask(p, cutoff_radius2(c), tx, ty), kept by the forward
             }
         }
         if (wave < kChunks) {
@@ -2063,6 +2067,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.order = reinterpret_cast<uint32_t *>(st + L.order);
     kp.items = reinterpret_cast<uint4 *>(st + L.items);
     kp.pair_rank = reinterpret_cast<uint32_t *>(st + L.pair_rank);
+    kp.touch = reinterpret_cast<uint16_t *>(st + L.pair_rank);
     kp.tile_off = reinterpret_cast<uint32_t *>(st + L.tile_off);
     kp.chunk_sum = reinterpret_cast<uint32_t *>(st + L.chunk_sum);
     kp.n_chunks = (kp.T + kScanChunk - 1) / kScanChunk;
