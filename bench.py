@@ -327,8 +327,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the scenario-B and single-view side measurements")
     ap.add_argument("--cpu-sample-views", type=int, default=0)
-    ap.add_argument("--frames-in-flight", dest="in_flight", type=int, default=int(os.environ.get("T4D_BENCH_IN_FLIGHT", "2")),
-                    help="independent frames in flight on as many HIP streams (1 = one frame after the other on one stream)")
+    ap.add_argument("--frames-in-flight", dest="in_flight", type=int, default=int(os.environ.get("T4D_BENCH_IN_FLIGHT", "0")),
+                    help="independent frames in flight on as many HIP streams (1 = one frame after the other on one stream; "
+                         "default: 2 for config 2, 1 for config 4, whose kernels fill the chip by themselves)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 64 if args.scaling == "strong" else 50
@@ -363,6 +364,8 @@ def main():
 
     import topo4d_amd
 
+    if args.in_flight < 1:
+        args.in_flight = 2 if args.config == "C2" else 1
     wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
     my_steps = args.steps // world if args.scaling == "strong" else args.steps
@@ -441,7 +444,7 @@ def main():
     if world == 1 and not args.no_extras:
         try:
             if args.opacity == "A":
-                wb = Workload(args.config, "B", dev)
+                wb = Workload(args.config, "B", dev, in_flight=args.in_flight)
                 wb.learn_capacity()
                 dtb, _ = timed_run(wb, my_steps, args.warmup, 0.1, lambda: torch.cuda.synchronize(dev), lambda x: x)
                 stb = wb.statuses()

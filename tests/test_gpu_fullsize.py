@@ -182,6 +182,15 @@ def test_c2_full_size_gradient_identities(c2):
     lhs = (gc["colors_precomp"].astype(np.float64) * rgb[None]).sum(axis=(1, 2))
     rhs = (c2["dc"].numpy().astype(np.float64) * out["color"]).sum(axis=(1, 2, 3))
     np.testing.assert_allclose(lhs, rhs, rtol=2e-4, atol=1e-9)
+    # (b') the same checksum from the backward itself: cotangent_dot[v] = <color, dL/dC> + <depth, dL/dD> + <alpha, dL/dA>
+    dev = torch.device("cuda")
+    dot = torch.empty(24, device=dev)
+    c2["batch"].backward(c2["dc"].to(dev), c2["dd"].to(dev), c2["da"].to(dev), cotangent_dot=dot)
+    terms = [c2["dc"].numpy().astype(np.float64) * out["color"], c2["dd"].numpy().astype(np.float64) * out["depth"],
+             c2["da"].numpy().astype(np.float64) * out["alpha"]]
+    want = sum(t.sum(axis=(1, 2, 3)) for t in terms)
+    scale = sum(np.abs(t).sum(axis=(1, 2, 3)) for t in terms)
+    assert (np.abs(dot.double().cpu().numpy() - want) <= 2e-6 * scale).all()
     # (c) screen-space gradient has no z component; culled Gaussians would have exactly zero gradient
     assert np.abs(g["means2D"][..., 2]).max() == 0
     for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp"):
