@@ -20,7 +20,15 @@ def _free_port():
 
 
 def _run(cmd, env):
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    """One retry when the PROCESS fails (a rendezvous port taken between _free_port() and the launcher's bind, a launcher
+    hiccup on a freshly booted box); what the processes print is never retried."""
+    for attempt in range(2):
+        if "--master-port" in cmd:
+            cmd = list(cmd)
+            cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}"
