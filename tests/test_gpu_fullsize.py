@@ -91,6 +91,9 @@ def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypa
         for k, v in g2.items():
             if v is not None:
                 assert not v.any(), k
+        dot = torch.full((3,), float("nan"), device="cuda")
+        batch2.backward(dc.cuda(), cotangent_dot=dot)
+        assert not dot.any()                            # ... and so is the per-view <outputs, cotangents>
     finally:
         topo4d_amd.set_sync_mode("checked")
         rasterizer._CAPACITY.clear()

@@ -141,7 +141,15 @@ def test_sh_colour_path(deg):
     rv["shs"][::7, 0, :] = -3.0     # force negative colours -> exercises the clamp flags
     from scaffold import scene
     dc, dd, da = scene.output_cotangents(V, H, W, seed=8, depth_alpha=True)
-    hip, hg, _ = util.hip_render(cams, rv, dc, dd, da)
+    hip, hg, batch = util.hip_render(cams, rv, dc, dd, da)
+    # the SH entry point of the per-Gaussian backward carries the per-view <outputs, cotangents> reduction as well
+    dot = torch.empty(V, device="cuda")
+    batch.backward(dc.cuda(), dd.cuda(), da.cuda(), cotangent_dot=dot)
+    terms = [dc.numpy().astype(np.float64) * hip["color"], dd.numpy().astype(np.float64) * hip["depth"],
+             da.numpy().astype(np.float64) * hip["alpha"]]
+    want = sum(t.sum(axis=(1, 2, 3)) for t in terms)
+    scale = sum(np.abs(t).sum(axis=(1, 2, 3)) for t in terms)
+    assert (np.abs(dot.double().cpu().numpy() - want) <= 2e-6 * scale).all()
     for v in range(V):
         r, g = util.c_oracle_render(cams[v], rv, dc[v], dd[v], da[v])
         check_outputs(hip, r.color, r.depth, r.alpha, v)
