@@ -2022,8 +2022,11 @@ int tile_grid(int n_tiles, int per_cu, int div)
         env_div = d ? atoi(d) : 0;
     }
     if (persistent) return min(n_tiles, device_cus() * per_cu);
-    if (env_div > 0) div = env_div;
-    return max(min(n_tiles, device_cus() * per_cu), (n_tiles + div - 1) / div);
+    if (env_div > 0) return max(min(n_tiles, device_cus() * per_cu), (n_tiles + env_div - 1) / env_div);
+    // ... up to kMaxGridPerCu workgroups per CU: beyond that (config 4: 393k tiles per launch) more workgroups only add prologues -
+    // the best div measured there was 12-16 (24-33k workgroups: 5.13 -> 4.79 ms per step), at config 2 (24.6k tiles) it is 2
+    constexpr int kMaxGridPerCu = 96;
+    return max(min(n_tiles, device_cus() * per_cu), min((n_tiles + div - 1) / div, device_cus() * kMaxGridPerCu));
 }
 
 // A launch of at most this many tiles runs the LATENCY builds of the render kernels: with <= 4 workgroups per CU in total
