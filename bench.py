@@ -41,6 +41,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+STRONG_JOB_FRAMES = 64          # BASELINE config 3: the 64-frame synthetic sequence
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 ACHIEVABLE_HBM_GBS = 6290.0
 
@@ -139,12 +140,15 @@ class Workload:
     same reason): `in_flight` of them are in flight on as many HIP streams, each with its own state buffers, so that the
     latency-bound binning kernels of one frame run beside the issue-bound render kernels of the other."""
 
-    def __init__(self, cfgname, opacity, dev, rank=0, world=1, in_flight=2, n_frames=64, resident=8):
+    def __init__(self, cfgname, opacity, dev, rank=0, world=1, in_flight=2, n_frames=64, resident=8, gather=None):
         from scaffold import reference_boundary as boundary, scene
         from topo4d_amd import ViewBatch, dist as t4d_dist, pack_views
         self.t4d_dist = t4d_dist
         self.cfg = cfg = dict(scene.CONFIGS[cfgname])
         self.dev, self.rank, self.world = dev, rank, world
+        # the loss all_gather runs whenever a process group exists - also a world-size-1 group (torchrun --nproc-per-node 1),
+        # so that the RCCL branch can be executed on a one-GPU box
+        self.gather = (world > 1) if gather is None else bool(gather)
         self.H, self.W, self.V = H, W, V = cfg["H"], cfg["W"], cfg["n_views"]
         params = scene.make_gaussians(cfg["n_lat"], cfg["n_lon"], opacity=opacity, sh_degree=cfg["sh_degree"], seed=0)
         self.P = params["means3D"].shape[0]
@@ -178,6 +182,10 @@ class Workload:
         self.loss_bufs = [torch.zeros(V, device=dev) for _ in range(nb)]
         self.gath_bufs = [torch.zeros(V * world, device=dev) for _ in range(nb)]
         self.pending = [None] * nb
+        # everything above was uploaded on the current stream: the side streams' first steps must not start before it
+        for st in self.streams:
+            if st is not None:
+                st.wait_stream(torch.cuda.current_stream(dev))
 
     def step(self, i):
         rv = self.rv_frames[i % len(self.rv_frames)]
@@ -192,7 +200,7 @@ class Workload:
             # per-view scalar loss term <colour, dL/dcolour>: the backward's replay ends holding exactly this inner product per
             # pixel, so it comes out of t4d_rasterize_backward (cotangent_dot), not out of a second pass over both images
             g = b.backward(self.dc, cotangent_dot=losses)
-            if self.world > 1:
+            if self.gather:
                 out, work = self.t4d_dist.gather_losses_async(losses, self.gath_bufs[k])
                 self.pending[k] = work
                 return out, [g]
@@ -350,8 +358,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # A process group exists whenever a launcher started us (torchrun sets RANK/WORLD_SIZE) - also for ONE rank, so that the
+    # RCCL path (init, async all_gather on the step's stream, barrier with device_ids) can be exercised on a one-GPU box.
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("T4D_DIST_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm; gloo only for dry runs
@@ -359,20 +369,21 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if args.scaling == "strong" and args.steps % world != 0:
-        raise SystemExit(f"--scaling strong: --steps {args.steps} (frame-steps of the whole job) must be a multiple of the {world} ranks")
+    # --scaling strong: the job is fixed; its frame-steps are rounded UP to a whole number per rank (64 for 1/2/4/8 ranks)
+    strong_job = args.steps if args.scaling == "strong" else STRONG_JOB_FRAMES
+    strong_steps_per_rank = -(-strong_job // world)
 
     import topo4d_amd
 
     if args.in_flight < 1:
         args.in_flight = 2 if args.config == "C2" else 1
-    wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight)
+    wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
-    my_steps = args.steps // world if args.scaling == "strong" else args.steps
+    my_steps = strong_steps_per_rank if args.scaling == "strong" else args.steps
 
     def barrier():
         wl.drain()
-        if world > 1:
+        if dist is not None:
             if dist.get_backend() == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
@@ -381,7 +392,7 @@ def main():
 
     def all_reduce_max(x):
         t = torch.tensor([x], device=dev, dtype=torch.float64)
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -394,6 +405,20 @@ def main():
         wl.sequential = False
         sequential = {"ms_per_step": round(1e3 * dts / my_steps, 4), "value": round(V * my_steps * world / dts, 2), "unit": "views/s",
                       "note": "frames_in_flight = 1: the same steps one after the other on one stream"}
+    # The OTHER scaling mode in the same line: the driver's one command per N must yield both the weak figure (`value`) and the
+    # number north_star asks for - the fixed 64-frame job of BASELINE config 3 split over the ranks (strong scaling).
+    other = None
+    if args.config == "C2":
+        o_steps = 20 if args.scaling == "strong" else max(1, min(strong_steps_per_rank, 512))
+        dto, _ = timed_run(wl, o_steps, min(args.warmup, 2), 0.05, barrier, all_reduce_max)
+        if args.scaling == "weak":
+            other = {"scaling": "strong", "job_frame_steps": o_steps * world, "steps_per_rank": o_steps,
+                     "ms_job": round(1e3 * dto, 4), "value": round(V * o_steps * world / dto, 2), "unit": "views/s",
+                     "note": f"fixed job: the {STRONG_JOB_FRAMES}-frame sequence of config 3 (rounded up to a whole number of frames "
+                             "per rank), sharded by frame; strong-scaling speed-up at N GPUs = this value at N / this value at 1"}
+        else:
+            other = {"scaling": "weak", "steps_per_rank": o_steps, "ms_per_step": round(1e3 * dto / o_steps, 4),
+                     "value": round(V * o_steps * world / dto, 2), "unit": "views/s"}
     sts = wl.statuses()
     if any(x.overflow for x in sts):
         raise SystemExit("pair arena overflowed during the timed region: result invalid")
@@ -436,7 +461,7 @@ def main():
                     "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels,
                     "valu": valu,
                     "measured_limiter": ("vector-ALU issue" if valu and valu.get("valu_busy", 0) > 0.6 else None)}
-    if world > 1:
+    if dist is not None:
         barrier()
 
     # ---- side measurements on one GPU: scenario B (unsaturated opacities) and the reference's one-view-per-call shape ----
@@ -473,7 +498,7 @@ def main():
                 cpu = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         out = {
             "metric": "rasterizer fwd+bwd views/sec", "value": round(value, 2), "unit": "views/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": (my_steps * world if args.scaling == "strong" else args.steps), "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / my_steps, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {V} views x {H}x{W}, P={P} vertex-bound Gaussians, "
@@ -484,11 +509,13 @@ def main():
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
                        "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "frames_in_flight": wl.F},
             "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "sequential": sequential,
+            ("weak" if args.scaling == "strong" else "strong"): other,
+            "dist_backend": (dist.get_backend() if dist is not None else None),
         }
         if last_losses is not None:
             out["gathered_losses_first_steps"] = last_losses
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

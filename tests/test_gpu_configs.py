@@ -49,6 +49,32 @@ def _bins_ok(st, v, P, radii_v, gx, gy, sample_tiles=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# config 1: one 256x256 view, 5k fixed-topology Gaussians, forward colour + depth (+ alpha)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opacity", ["A", "B"])
+def test_c1_single_view_forward_colour_depth_alpha(opacity, render_build):
+    """BASELINE config 1's exact workload (scene.CONFIGS["C1"]): the plumbing case - one camera, P = 5,000, forward only,
+    through the drop-in module (the call of train.py:307), every pixel of colour, depth and alpha against the C oracle."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from scaffold import scene
+    cfg = scene.CONFIGS["C1"]
+    H, W = cfg["H"], cfg["W"]
+    rv, cams = util.make_scene(cfg["n_lat"], cfg["n_lon"], H, W, cfg["n_views"], opacity=opacity, seed=0)
+    assert (rv["means3D"].shape[0], H, W, len(cams)) == (5000, 256, 256, 1)
+    cam = util.to_device(cams, "cuda")[0]
+    with torch.no_grad():
+        im, radius, depth, alpha = GaussianRasterizer(raster_settings=cam)(
+            means3D=rv["means3D"].cuda(), means2D=torch.zeros_like(rv["means3D"]).cuda(), opacities=rv["opacities"].cuda(),
+            colors_precomp=rv["colors_precomp"].cuda(), scales=rv["scales"].cuda(), rotations=rv["rotations"].cuda())
+    assert im.shape == (3, H, W) and depth.shape == (1, H, W) and alpha.shape == (1, H, W) and radius.shape == (5000,)
+    r, _ = util.c_oracle_render(cams[0], rv)
+    np.testing.assert_array_equal(radius.cpu().numpy(), r.radii)
+    hip = dict(color=im[None].cpu().numpy(), depth=depth[None].cpu().numpy(), alpha=alpha[None].cpu().numpy())
+    check_outputs(hip, r.color, r.depth, r.alpha, 0)          # max_flips = 0: every pixel within 2e-5
+    assert (alpha > 0.5).float().mean() > 0.2                 # the head really is in the picture
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # config 4: 24 x 2048^2, P = 120k, SH degree 3
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opacity", ["A", "B"])
@@ -224,8 +250,11 @@ def test_c5_texture_bake_8192_bit_identical_to_reference_code():
 # ------------------------------------------------------------------------------------------------------------------
 # randomised parity (formerly tools/stress_parity.py)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("trial", range(12))
-def test_randomised_scenes_against_c_oracle(trial):
+def _randomised_trial(trial, strict=False):
+    """One seeded random scene (size, scale, anisotropy, orientation, opacity scenario, with/without depth+alpha cotangents)
+    against the C oracle.  At most two pixels per view may take a discrete decision (alpha >= 1/255, T < 1e-4) the other way
+    than glibc's expf does; a Gaussian may miss the gradient tolerance ONLY with such a pixel inside its 3-sigma square
+    (check_grads_modulo_flips).  strict=True (tools/soak_parity.py --strict): no such allowance for the gradients."""
     from scaffold import scene
     rng = np.random.default_rng(1000 + trial)
     H, W = int(rng.integers(40, 150)), int(rng.integers(40, 150))
@@ -242,12 +271,42 @@ def test_randomised_scenes_against_c_oracle(trial):
     hip, hg, batch = util.hip_render(cams, rv, dc, dd if use_da else None, da if use_da else None)
     st = util.decode_state(batch)
     assert st["status"][0] == 0
+    n_flips = 0
     for v in range(V):
         r, g = util.c_oracle_render(cams[v], rv, dc[v], dd[v] if use_da else None, da[v] if use_da else None)
         np.testing.assert_array_equal(hip["radii"][v], r.radii)
-        check_n_contrib(st["n_contrib"][v], r.state()["n_contrib"], max_flips=2)
-        check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=2)
-        check_grads(hg, g, v)
+        flips = flipped_pixels(hip, v, r, st["n_contrib"][v])
+        assert len(flips) <= 2, f"view {v}: {len(flips)} pixels took a discrete decision the other way"
+        check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=len(flips))
+        if strict:
+            check_grads(hg, g, v)
+        else:
+            check_grads_modulo_flips(hg, g, v, flips, st["xy"][v], hip["radii"][v])
+        n_flips += len(flips)
+    return n_flips
+
+
+@pytest.mark.parametrize("trial", range(12))
+def test_randomised_scenes_against_c_oracle(trial):
+    _randomised_trial(trial)
+
+
+def test_randomised_soak_both_builds(monkeypatch):
+    """Time-boxed soak inside the suite: at least 50 further seeds under BOTH builds of the render kernels (more while the box
+    has time left).  Round 2's soak of 400 runs (tools/soak_parity.py) had one scene miss the plain gradient tolerance because
+    of ONE threshold pixel; with the flip-aware check every run must be green."""
+    import time
+    t0 = time.time()
+    done = flips = 0
+    for trial in range(12, 412):
+        for tiles in ("0", "1000000000"):                    # throughput build, latency build
+            monkeypatch.setenv("T4D_LATENCY_TILES", tiles)
+            flips += _randomised_trial(trial)
+        done += 1
+        if done >= 50 and time.time() - t0 > 150.0:
+            break
+    assert done >= 50
+    print(f"soak: {done} seeds x 2 builds, {flips} threshold pixels in total, {time.time() - t0:.0f} s")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -285,9 +344,11 @@ def test_culling_edges_opacity_at_one_over_255():
     hip, hg, batch = util.hip_render([cam], rv, dc * 1e3, dd, da)
     r, gref = util.c_oracle_render(cam, rv, dc[0] * 1e3, dd[0], da[0])
     np.testing.assert_array_equal(hip["radii"][0], r.radii)
-    check_n_contrib(util.decode_state(batch)["n_contrib"][0], r.state()["n_contrib"], max_flips=4)
-    check_outputs(hip, r.color, r.depth, r.alpha, 0, max_flips=4)
-    check_grads(hg, gref, 0, max_bad_rows=4)
+    st = util.decode_state(batch)
+    flips = flipped_pixels(hip, 0, r, st["n_contrib"][0])
+    assert len(flips) <= 4
+    check_outputs(hip, r.color, r.depth, r.alpha, 0, max_flips=len(flips))
+    check_grads_modulo_flips(hg, gref, 0, flips, st["xy"][0], hip["radii"][0])
 
 
 def test_culling_edges_needles_and_sub_block_corners():
@@ -327,6 +388,7 @@ def test_culling_edges_needles_and_sub_block_corners():
     for v in range(2):
         r, gref = util.c_oracle_render(cams[v], rv, dc[v], dd[v], da[v])
         np.testing.assert_array_equal(hip["radii"][v], r.radii)
-        check_n_contrib(st["n_contrib"][v], r.state()["n_contrib"], max_flips=2)
-        check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=2)
-        check_grads(hg, gref, v, rel=5e-4)
+        flips = flipped_pixels(hip, v, r, st["n_contrib"][v])
+        assert len(flips) <= 2
+        check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=len(flips))
+        check_grads_modulo_flips(hg, gref, v, flips, st["xy"][v], hip["radii"][v])

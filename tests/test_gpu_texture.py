@@ -92,13 +92,18 @@ def test_dense_attribute_interpolation_bit_exact_vs_reference_golden():
     np.testing.assert_array_equal(out.cpu().numpy(), ref.astype(np.float32))
 
 
-def _sharded_bake_worker(rank, world, port, out_path):
+def _sharded_bake_worker(rank, world, port, out_path, backend="gloo"):
     import os
     import torch.distributed as dist
     from topo4d_amd import texture
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share cuda:0 in this test
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":                                                 # RCCL: one rank per GPU, so world == 1 on the test box
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0 in this test
     try:
         rng = np.random.default_rng(7)
         n, res = 40, 250
@@ -124,4 +129,17 @@ def test_sharded_bake_two_ranks_equals_single_bake(tmp_path):
     mp.spawn(_sharded_bake_worker, args=(2, port, out), nprocs=2, join=True)
     a, b = np.load(out), np.load(out + ".single.npy")
     assert a.shape == (250, 250, 3) and a.dtype == np.uint8 and a.any()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_sharded_bake_through_rccl_with_one_rank(tmp_path):
+    """The RCCL ("nccl") branch of the band gather executed for real: a process group of ONE rank on the test box's one GPU -
+    init with device_id, all_gather_into_tensor of the band on the device, destroy - before an 8-GPU node ever sees it."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sharded_rccl.npy")
+    mp.spawn(_sharded_bake_worker, args=(1, port, out, "nccl"), nprocs=1, join=True)
+    a, b = np.load(out), np.load(out + ".single.npy")
+    assert a.shape == (250, 250, 3) and a.any()
     np.testing.assert_array_equal(a, b)

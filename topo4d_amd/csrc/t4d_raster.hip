@@ -893,7 +893,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
 // Bins longer than kSortLdsCap keys (dense passes: 191 of 11,544 non-empty bins at P = 1M, 4096x3008, the longest 15,693 keys)
 // get a whole CU each: 1024 threads and 128 KiB of LDS sort up to kLongCap keys without touching memory in between (runs of
 // 64 in registers, then log2(n/64) ranking merges in LDS); even longer bins fall back to LDS-sorted chunks merged in global
-// memory.  Work items are ordered by length, so the long bins are items 0, 1, ... and a workgroup stops at the first short one.
+// memory.  Work items are ordered by length class, so the long bins come first and a workgroup stops at the first bin of a shorter class.
 __global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
 {
     __shared__ unsigned long long s_keys[kLongCap];
@@ -903,7 +903,10 @@ __global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
         const uint4 it = kp.items[item];
         const int v = (int)(it.x >> 20);
         const uint32_t off = it.y, n = it.z;
-        if (n <= (uint32_t)kSortLdsCap) break;
+        // The list is ordered by length CLASS (floor(log2 n)) only: a bin of exactly kSortLdsCap keys (k_sort_tiles' share) can
+        // sit in front of longer bins of the same class, so it is skipped; the first bin of a shorter class ends the loop.
+        if (n < (uint32_t)kSortLdsCap) break;
+        if (n == (uint32_t)kSortLdsCap) continue;
         unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
         if (n <= (uint32_t)kLongCap) sort_chunk_lds<kLongBlock, kLongCap>(keys, n, s_keys, tid, wave, lane);
         else sort_bin_chunked<kLongBlock, kLongCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);

@@ -5,7 +5,8 @@ The reference is single-process / single-GPU; this is the one 
 every (frame, view) render reads the same replicated Gaussians and its own camera, so units are independent
 (SURVEY.md §8e).  Rank r of W takes units {u : u mod W == r}.  No data-path collective exists; the only exchange
 is an all_gather of the per-view scalar photometric losses (a few floats per rank) — RCCL on GPU ("nccl" backend
-is RCCL on ROCm), gloo in the CPU tests.
+is RCCL on ROCm), gloo in the CPU tests.  The collectives run whenever a process group is initialised, also one of a
+single rank: that is how the RCCL calls are exercised on a one-GPU test box (tests/test_gpu_multirank.py).
 """
 from __future__ import annotations
 
@@ -29,7 +30,7 @@ def gather_losses(local: torch.Tensor, n_units: int = None) -> torch.Tensor:
     """all_gather of per-unit scalar losses.  `local` is this rank's 1-D tensor (round-robin shard of n_units
     units; ranks may hold different counts).  Returns the losses of ALL units in unit order, on every rank."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     if local.is_cuda and dist.get_backend() != "nccl":        # gloo dry runs: stage through the host
@@ -58,7 +59,7 @@ def gather_losses_async(local: torch.Tensor, out: torch.Tensor):
     world*local.numel() elements in rank-major order (out.view(world,-1).t() is unit order) and, like `local`, must not be
     rewritten before `work.wait()`."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         out[: local.numel()].copy_(local)
         return out, None
     if local.is_cuda and dist.get_backend() != "nccl":        # gloo dry runs: synchronous, through the host
@@ -74,7 +75,7 @@ def all_reduce_grads(grads: Sequence[torch.Tensor]) -> None:
     """Optional data-parallel training step: sum the (already view-summed) parameter gradients over ranks.
     Changes the optimisation schedule versus train.py:661-673 (one Adam step per view) — see DESIGN.md."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -98,7 +99,7 @@ def gather_bands(band: torch.Tensor, n_rows: int) -> torch.Tensor:
     """all_gather of per-rank row bands ([rows_r, ...], band_bounds order) into the full [n_rows, ...] tensor on every rank.
     Bands may differ by one row; they are padded to the tallest for the collective."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return band
     world = dist.get_world_size()
     if band.is_cuda and dist.get_backend() != "nccl":         # gloo dry runs: stage through the host

@@ -97,7 +97,7 @@ def bake_texture_sharded(uvs, colors, faces, res: int = 1024, device="cuda") -> 
     bake_texture: the per-texel result does not depend on the band it is computed in."""
     import torch.distributed as dist
     from . import dist as t4d_dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return bake_texture(uvs, colors, faces, res, device)
     r0, r1 = t4d_dist.band_bounds(res, dist.get_rank(), dist.get_world_size())
     uv_coords = process_uv(uvs, res, res)
