@@ -80,7 +80,7 @@ def decode_state(batch):
     lib = _lib.load()
     prob = batch.prob
     offs = (C.c_uint64 * 16)()
-    has_sh = batch.inputs[6] is not None
+    has_sh = batch.prob.sh_coeffs > 0
     rc = lib.t4d_debug_state_layout(C.byref(prob), int(has_sh), offs, 16)
     assert rc == 0
     names = ["status", "view_total", "view_cursor", "tile_count", "bucket_fill", "tile_off", "xy", "depth",
@@ -91,16 +91,23 @@ def decode_state(batch):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     cap = prob.pair_capacity
     f = lambda name, n, dt: raw[o[name]: o[name] + n * np.dtype(dt).itemsize].view(dt)
+    tile_count = f("tile_count", V * T, np.uint32).reshape(V, T)
+    # The forward writes no replay state (final_T, n_contrib) for EMPTY tiles - the backward never visits them - so those
+    # pixels hold whatever the allocation held.  They are presented here with the values the state means there: T = 1, no
+    # contributor (what the oracle holds for a background pixel).
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    empty = np.repeat(np.repeat((tile_count == 0).reshape(V, gy, gx), 16, axis=1), 16, axis=2)[:, :H, :W]
+    final_T = np.where(empty, np.float32(1.0), f("final_T", V * H * W, np.float32).reshape(V, H, W))
+    n_contrib = np.where(empty, np.uint32(0), f("n_contrib", V * H * W, np.uint32).reshape(V, H, W))
     return dict(
         status=f("status", 4, np.uint32), view_total=f("view_total", V, np.uint32),
-        tile_count=f("tile_count", V * T, np.uint32).reshape(V, T),
+        tile_count=tile_count,
         tile_off=f("tile_off", V * T, np.uint32).reshape(V, T),
         xy=f("xy", V * P * 2, np.float32).reshape(V, P, 2), depth=f("depth", V * P, np.float32).reshape(V, P),
         conic_opacity=f("conic_opacity", V * P * 4, np.float32).reshape(V, P, 4),
         pair_off=f("pair_off", V * P, np.uint32).reshape(V, P),
         keys=f("keys", V * cap, np.uint64).reshape(V, cap),
-        final_T=f("final_T", V * H * W, np.float32).reshape(V, H, W),
-        n_contrib=f("n_contrib", V * H * W, np.uint32).reshape(V, H, W), T=T, cap=cap)
+        final_T=final_T, n_contrib=n_contrib, T=T, cap=cap)
 
 
 def rel_err(a, b):

@@ -1,7 +1,8 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import topo4d_amd
-from scaffold import reference_boundary as boundary, scene, ViewBatch, pack_views, rasterize_views
+from scaffold import reference_boundary as boundary, scene
+from topo4d_amd import ViewBatch, pack_views, rasterize_views
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 dev = torch.device("cuda"); H, W = 512, 375
 p = scene.make_gaussians(69, 120, opacity="A", seed=0)

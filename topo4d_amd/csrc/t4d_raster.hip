@@ -928,6 +928,17 @@ __global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Counting build (-DT4D_COUNT, tools/count_lanes.py; never defined in the shipped library): what the render kernels' visit loops
+// do, summed over a launch - [0..7] backward, [8..15] forward:
+//   +0 non-empty tiles   +1 live wave-batches   +2 wave-steps (one step = four DPP rows x 16 pixels)   +3 row-visits (list entries)
+//   +4 lanes that blend / contribute (of 64 per wave-step)
+#ifdef T4D_COUNT
+__device__ unsigned long long g_count[16];
+#define T4D_COUNT_ADD(IDX_, VAL_) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_count[(IDX_)], (unsigned long long)(VAL_)); } while (0)
+#else
+#define T4D_COUNT_ADD(IDX_, VAL_) do { } while (0)
+#endif
+
 __device__ __forceinline__ void tile_pixel(int tid, int tx, int ty, int &px, int &py)
 {
     const int w = tid >> 6, r = (tid >> 4) & 3, i = tid & 15;
@@ -1120,6 +1131,8 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         for (int r = 0; r < 4; r++) pad_visit_list<kU>(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kRec));
         __builtin_amdgcn_wave_barrier();
         const unsigned short *list = s_list[wave][row];
+        T4D_COUNT_ADD(9, 1); T4D_COUNT_ADD(11, cnts[0] + cnts[1] + cnts[2] + cnts[3]);
+        if (b == 0 && wave == 0) T4D_COUNT_ADD(8, 1);
 #if T4D_ABL == 5
         nsteps = 0;
 #endif
@@ -1164,7 +1177,9 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 Wt += w;
                 T = ok ? test_T : T;
                 last_e = ok ? e[u] : last_e;
+                T4D_COUNT_ADD(12, __builtin_popcountll(live & ~below));
             }
+            T4D_COUNT_ADD(10, kU);
             if (done_m == ~0ull) break;
         }
         done = __builtin_amdgcn_inverse_ballot_w64(done_m);
@@ -1173,8 +1188,10 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     if (inside) {
         const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
         const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
-        kp.final_T[(size_t)v * HW + pix] = T;
-        kp.n_contrib[(size_t)v * HW + pix] = last_contributor;
+        if (n != 0) {                                 // the backward never visits an empty tile: no replay state for it
+            kp.final_T[(size_t)v * HW + pix] = T;
+            kp.n_contrib[(size_t)v * HW + pix] = last_contributor;
+        }
         float *oc = kp.out_color + (size_t)v * 3 * HW;
         oc[pix] = C0 + T * vr[35];
         oc[HW + pix] = C1 + T * vr[36];
@@ -1286,7 +1303,7 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 // DA = the caller supplied dL/ddepth and/or dL/dalpha.  Topo4D discards depth and alpha (train.py:307), so its backward
 // runs the DA = false instantiation, which carries neither the two extra suffix accumulators nor their products.
 #ifndef T4D_BWD_WAVES
-#define T4D_BWD_WAVES 5
+#define T4D_BWD_WAVES 5                  // = workgroups per CU (30.8 KB of LDS each); 4 is 14 % slower, 6 spills (round-3 sweep)
 #endif
 #define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_BWD_WAVES, LAT ? 2 : T4D_BWD_WAVES)))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
@@ -1305,7 +1322,7 @@ template <bool DA, bool LAT>
 __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
     constexpr int kSlabs = LAT ? 16 : 4;
-    constexpr int kChunks = kBwdBatch / 64;
+    constexpr int kChunks = (kBwdBatch + 63) / 64;
     constexpr int kListStride = kBwdBatch + 4;
     // A staged splat is ONE 40-byte record - scaled conic + opacity (16) | rgb + depth (16) | xy (8) - exactly as long as a slab
     // entry (ten floats), and list entries are slot * 40: the byte offset of BOTH, so a step spends no vector instruction on
@@ -1506,6 +1523,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             for (int c2 = 0; c2 < kChunks; c2++) conflict_s[c2] = uniform_u64(conflict[c2]);
             const unsigned short *list = s_list[wave][row];
             const unsigned char *rec_b = s_rec;
+            T4D_COUNT_ADD(1, 1); T4D_COUNT_ADD(2, (nsteps + 3) & ~3); T4D_COUNT_ADD(3, cnts[0] + cnts[1] + cnts[2] + cnts[3]);
+            if (bi == nb - 1 && wave == 0) T4D_COUNT_ADD(0, 1);
             // LAT: lanes that keep no sum write (zeros plus whatever) into distinct floats of the null splat's row of their slab
             unsigned char *slab = LAT ? reinterpret_cast<unsigned char *>(my_slot >= 0 ? &s_acc[wave * 4 + row][0][my_slot]
                                                                                       : &s_acc[wave * 4 + row][kNull][(lane & 15) % kAcc])
@@ -1546,6 +1565,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
+                    T4D_COUNT_ADD(4, __builtin_popcountll(__ballot(contrib)));
                     const v2f d = ds[u];
                     const float G = Gs[u], alpha = alphas[u];
                     float *dst = reinterpret_cast<float *>(slab + (LAT ? (ee[u] & slab_and) : ee[u]));
@@ -2274,6 +2294,18 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;
 }
+
+#ifdef T4D_COUNT
+T4D_EXPORT int t4d_debug_read_counters(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_count), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[16] = { 0 };
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_count), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 
 #ifdef T4D_TIMING
 T4D_EXPORT int t4d_debug_read_timing(unsigned long long *out, int n)

@@ -92,7 +92,11 @@ class _FusedPhotometric(torch.autograd.Function):
 
 def photometric_loss(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tensor = None, cam_c: torch.Tensor = None) -> torch.Tensor:
     """Per-view loss [V] for im, gt [V,3,H,W] (cam_m, cam_c [V,3] optional) — train.py:310,315 fused on the GPU.
-    Differentiable w.r.t. im, cam_m, cam_c."""
+    Differentiable w.r.t. im, cam_m, cam_c.  The reference's own call shape - ONE [3,H,W] render and target (cam_m, cam_c [3])
+    - returns a scalar."""
+    if im.dim() == 3:
+        one = lambda t: None if t is None else t.unsqueeze(0)
+        return _FusedPhotometric.apply(im.unsqueeze(0), one(gt), one(cam_m), one(cam_c))[0]
     return _FusedPhotometric.apply(im, gt, cam_m, cam_c)
 
 
@@ -119,6 +123,7 @@ class _FusedMaskedL1(torch.autograd.Function):
         if not im.is_cuda:
             raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
         im_c, gt_c, m_c = im.float().contiguous(), gt.float().contiguous(), mask.float().contiguous()
+        ctx.im_dtype = im.dtype
         V, _, H, W = im_c.shape
         dev = im_c.device
         loss = torch.empty(V, dtype=torch.float32, device=dev)
@@ -136,10 +141,14 @@ class _FusedMaskedL1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         (d_im,) = ctx.saved_tensors
-        return d_im * go.view(-1, 1, 1, 1), None, None
+        g = d_im * go.view(-1, 1, 1, 1)
+        return (g if g.dtype == ctx.im_dtype else g.to(ctx.im_dtype)), None, None
 
 
 def masked_l1_loss(im: torch.Tensor, gt: torch.Tensor, filtered_mask: torch.Tensor) -> torch.Tensor:
     """Per-view masked L1 [V] for im, gt, filtered_mask [V,3,H,W] - train.py:394-405 fused on the GPU (loss + dL/dim in two
-    launches).  Differentiable w.r.t. im."""
+    launches).  Differentiable w.r.t. im.  The reference's own call shape (get_loss_dense: ONE [3,H,W] render, target and
+    mask) returns a scalar."""
+    if im.dim() == 3:
+        return _FusedMaskedL1.apply(im.unsqueeze(0), gt.unsqueeze(0), filtered_mask.unsqueeze(0))[0]
     return _FusedMaskedL1.apply(im, gt, filtered_mask)

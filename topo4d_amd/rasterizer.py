@@ -385,6 +385,9 @@ class ViewBatch:
         <color, dL_dcolor> + <depth, dL_ddepth> + <alpha, dL_dalpha> per view (a by-product of the replay)."""
         if self.state is None:
             raise RuntimeError("backward() before forward()")
+        if self.inputs is None or self.inputs[0] is None:
+            raise RuntimeError("this ViewBatch's inputs are owned by an autograd graph (GaussianRasterizer / rasterize_views): "
+                               "call .backward() on the loss instead of ViewBatch.backward()")
         dev = self.device
         means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs = self.inputs
         V, P, H, W = self.V, int(means3D.shape[0]), self.H, self.W
@@ -467,7 +470,7 @@ class _RasterizeViews(torch.autograd.Function):
         # update between forward and backward raise instead of silently differentiating at the wrong point
         ctx.input_slots = [i for i, t in enumerate(batch.inputs) if t is not None]
         ctx.save_for_backward(*[batch.inputs[i] for i in ctx.input_slots])
-        batch.inputs = tuple(None if t is None else True for t in batch.inputs)     # ownership moved to the ctx
+        batch.inputs = None                  # ownership moved to the ctx (a direct ViewBatch.backward() now raises clearly)
         ctx.set_materialize_grads(False)     # unused depth/alpha outputs arrive as None -> cheaper backward kernel
         ctx.mark_non_differentiable(radii)
         ctx.shapes = (means3D.shape, means2D.shape if means2D is not None else None, opacities.shape)
@@ -483,6 +486,7 @@ class _RasterizeViews(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros(batch.V, 3, batch.H, batch.W, dtype=torch.float32, device=batch.device)
         g = batch.backward(grad_color, grad_depth, grad_alpha)
+        batch.inputs = None                  # the batch (kept by GraphedViews / _BATCH_LOG) must not keep the inputs alive
         red = (lambda t: None if t is None else t.sum(0)) if batch.V > 1 else \
               (lambda t: None if t is None else t[0])
         shp3, shp2, shpo = ctx.shapes
