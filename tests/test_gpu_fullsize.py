@@ -261,7 +261,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
     call = lambda r, sc=1.0: r(d["means3D"], None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * sc,
                                rotations=d["rotations"])
     ref = [[t.clone() for t in call(r)] for r in R]
-    rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()
+    rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
     topo4d_amd.set_sync_mode("auto")
     try:
         for it in range(4):                                   # first call per camera is checked, the rest are not
@@ -287,7 +287,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
         for a, b in zip(out, chk):
             assert torch.equal(a, b)
         # an abrupt jump (scales x6 from one call to the next) overflows once and is REPORTED at the following call
-        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()
+        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
         call(R[0]); call(R[0])
         leaf = d["means3D"].clone().requires_grad_(True)
         out_t = R[0](leaf, None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * 6.0, rotations=d["rotations"])
@@ -302,4 +302,4 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
             assert torch.equal(a, b)
     finally:
         topo4d_amd.set_sync_mode("checked")
-        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._INFLIGHT.clear()
+        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()

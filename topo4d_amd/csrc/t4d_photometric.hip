@@ -25,27 +25,30 @@ int t4d_internal_fail(int code, const char *fmt, const char *a);
 
 namespace {
 
-// One workgroup = a 64 x 16 pixel tile of one channel of one view, 256 threads.  The separable 11-tap window runs as a
-// vertical pass (each task: one column, FOUR consecutive output rows, 14 input rows read once into registers) followed by
-// a horizontal pass (each thread: one row, FOUR consecutive output columns) — a register sliding window, so an output costs
-// ~3.5 + 7 LDS reads instead of 11 + 11 x (number of filtered maps).
-#ifndef T4D_PH_TW
-#define T4D_PH_TW 64
-#endif
-constexpr int kTW = T4D_PH_TW, kTH = 16;  // tile (kTW a multiple of 4)
+// One kernel, no intermediate in memory.  (Rounds 1-2 ran two tile kernels with the three adjoint maps going through HBM in
+// between: 302 MB written and - with the halo - 570 MB read back per 24 x 512^2 views, 0.46 ms of kernels against a traffic
+// floor of ~0.1 ms.)  A workgroup of 128 threads owns a vertical STRIP of one channel of one view - up to 118 output columns, a
+// segment of rows - and streams down it one image row per iteration; every thread owns ONE column:
+//   * the row's (x', gt) go to LDS; each thread takes the 11-tap HORIZONTAL sums of (x, y, x^2, y^2, xy) at its column and
+//     pushes them into a window of the last eleven rows that lives in REGISTERS; the VERTICAL sums over that window are the
+//     five filtered maps at the row five behind - SSIM, loss terms and the three adjoint values D1..D3 of that pixel;
+//   * the adjoint row goes to LDS (its columns reach five beyond the strip on either side, which is why a strip of 118 uses
+//     128 threads); each thread takes its horizontal 11-tap sums, pushes them into a second register window, and the
+//     vertical sums over it give G*D1, G*D2, G*D3 at the row five further behind: dL/dx' and the affine backward.
+// Both 2-D windows are separable and symmetric, so adjoint = same filter.  Rows are unrolled eleven at a time so that the
+// window slots are compile-time register names (no shifting).  One barrier per row; the only redundancy is the warm-up of a
+// segment (20 rows) and the 10 halo columns of a strip.
 constexpr int kR = 5;              // window radius (11 taps)
-constexpr int kIW = kTW + 2 * kR;  // 74
-constexpr int kIH = kTH + 2 * kR;  // 26
-constexpr int kPitch = (kIW + 2) | 1;         // row pitch (elements) of the vertically filtered maps: odd multiple keeps the
-                                   // lane->row mapping of the horizontal pass free of LDS bank conflicts
-constexpr int kBlock = 256;
+constexpr int kFT = 128;           // threads per workgroup = columns of the first stage
+constexpr int kFTW = kFT - 2 * kR; // output columns of a strip (at most)
+constexpr int kBlock = 256;        // (k_photo_final and the masked-L1 kernels)
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct PhP {
-    int V, H, W, tx, ty;
+    int V, H, W, tx, ty;           // tx strips of tw columns, ty segments of th rows per (view, channel)
+    int tw, th;
     const float *im, *gt, *cam_m, *cam_c, *weight;
     float *loss, *dL_dim, *dL_dm, *dL_dc;
-    float4 *D;           // [V*3*H*W] adjoint maps (D1, D2, D3, -)
     float *part_loss;    // [V*3*tiles][2]  (sum |x'-y|, sum S)
     float *part_cam;     // [V*3*tiles][2]  (sum g'*(x'-c), sum g')
     float win[11];
@@ -55,180 +58,167 @@ __device__ __forceinline__ float block_sum(float v, float *s_red)
 {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
     __syncthreads();
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
-    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    float t = s_red[0];
+    for (int w = 1; w < nw; w++) t += s_red[w];
+    return t;
 }
 
-__global__ __launch_bounds__(kBlock) void k_photo_stats(const PhP P)
+template <int N> struct IC { static constexpr int value = N; };
+
+__global__ __launch_bounds__(kFT) void k_photo_fused(const PhP P)
 {
-    __shared__ float2 s_in[kIH][kIW + 1];                // (x', gt) with halo, zero padded
-    __shared__ float4 s_v4[kTH][kPitch];                 // vertically filtered (x, y, x^2, y^2)
-    __shared__ float s_v1[kTH][kPitch];                  // vertically filtered x*y
+    constexpr int kInW = kFT + 2 * kR;                   // input columns a row needs: 138
+    __shared__ float2 s_in[2][kInW];                     // (x', gt) of the current row, zero padded
+    __shared__ float s_d[2][3][kFT + 2];                 // adjoint row (D1, D2, D3) at the first stage's columns
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int vc = blockIdx.z, v = vc / 3;
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const int xs = blockIdx.x * P.tw, xe = min(xs + P.tw, P.W);              // output columns [xs, xe)
+    const int y0 = blockIdx.y * P.th, y1 = min(y0 + P.th, P.H);              // output rows [y0, y1)
     const size_t HW = (size_t)P.H * P.W;
     const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
     const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
-    for (int i = tid; i < kIH * kIW; i += kBlock) {
-        const int r = i / kIW, c = i - r * kIW;
-        const int yy = y0 + r - kR, xx = x0 + c - kR;
-        float a = 0.f, b = 0.f;                                  // zero padding (external.py:86 padding=5)
-        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
-            a = em * im[(size_t)yy * P.W + xx] + cc;
-            b = gt[(size_t)yy * P.W + xx];
-        }
-        s_in[r][c] = make_float2(a, b);
+    const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
+    const float g = -0.2f * wv / N;                      // dL/dS
+    const float l1w = 0.8f * wv / N;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = P.win[k];
+
+    const int gx1 = xs - kR + tid;                       // this thread's column in the first stage
+    const bool col1 = gx1 >= 0 && gx1 < P.W;
+    const bool own1 = tid >= kR && gx1 < xe;             // ... which belongs to this strip's outputs (loss terms are counted once)
+    const int gx2 = xs + tid;                            // ... and in the second stage
+    const bool col2 = gx2 < xe;
+    // columns this thread loads of every input row: xs - 10 + tid and (the first ten threads) 128 further right
+    const int lx0 = xs - 2 * kR + tid, lx1 = lx0 + kFT;
+    const bool l0 = lx0 >= 0 && lx0 < P.W, l1 = tid < 2 * kR && lx1 < P.W;
+
+    float h[11][5], hd[11][3];                           // the two register windows (slots are compile-time indices)
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int m = 0; m < 5; m++) h[k][m] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 3; m++) hd[k][m] = 0.f;
     }
-    __syncthreads();
-    for (int t = tid; t < kIW * (kTH / 4); t += kBlock) {        // vertical pass: column `col`, output rows r0..r0+3
-        const int run = t / kIW, col = t - run * kIW, r0 = run * 4;
-        float sx[4] = { 0, 0, 0, 0 }, sy[4] = { 0, 0, 0, 0 }, sxx[4] = { 0, 0, 0, 0 }, syy[4] = { 0, 0, 0, 0 }, sxy[4] = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 14; k++) {
-            const float2 ab = s_in[r0 + k][col];
-            const float a = ab.x, b = ab.y, aa = a * a, bb = b * b, abp = a * b;
+    for (int m = 0; m < 3; m++) s_d[0][m][tid] = s_d[1][m][tid] = 0.f;      // the first iteration's second stage reads a row nobody wrote
+    float sum_l1 = 0.f, sum_s = 0.f, sum_gm = 0.f, sum_gc = 0.f;
+    const int i_first = y0 - 2 * kR, i_last = y1 + 2 * kR;      // input rows i_first .. i_last (the last one only drains)
+
+    // prefetch of the first row
+    float pa0 = 0.f, pb0 = 0.f, pa1 = 0.f, pb1 = 0.f;
+    auto fetch = [&](int i) {
+        pa0 = pb0 = pa1 = pb1 = 0.f;
+        if (i >= 0 && i < P.H) {
+            const size_t o = (size_t)i * P.W;
+            if (l0) { pa0 = im[o + lx0]; pb0 = gt[o + lx0]; }
+            if (l1) { pa1 = im[o + lx1]; pb1 = gt[o + lx1]; }
+        }
+    };
+    fetch(i_first);
+
+    auto row = [&](const int i, auto J_) {
+        constexpr int J = decltype(J_)::value;           // slot of this row in both windows
+        const int buf = i & 1;
+        // ---- this row's inputs to LDS (zero padding outside the image: external.py:86 padding=5), next row's loads in flight
+        {
+            const bool in_img = i >= 0 && i < P.H;
+            s_in[buf][tid] = (in_img && l0) ? make_float2(em * pa0 + cc, pb0) : make_float2(0.f, 0.f);
+            if (tid < 2 * kR) s_in[buf][tid + kFT] = (in_img && l1) ? make_float2(em * pa1 + cc, pb1) : make_float2(0.f, 0.f);
+        }
+        fetch(i + 1);
+        // the pixel of the OUTPUT row of this iteration (eleven rows behind): needed at the very end, requested now
+        const int o_row = i - 2 * kR - 1;
+        const bool emit = col2 && o_row >= y0 && o_row < y1;
+        float o_im = 0.f, o_gt = 0.f;
+        if (emit) { o_im = im[(size_t)o_row * P.W + gx2]; o_gt = gt[(size_t)o_row * P.W + gx2]; }
+        __syncthreads();
+        // ---- first stage, horizontal: 11 taps of (x, y, x^2, y^2, xy) at this thread's column
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int tap = k - j;
-                if (tap >= 0 && tap < 11) {
-                    const float w = P.win[tap];
-                    sx[j] += w * a; sy[j] += w * b; sxx[j] += w * aa; syy[j] += w * bb; sxy[j] += w * abp;
-                }
+            for (int k = 0; k < 11; k++) {
+                const float2 ab = s_in[buf][tid + k];
+                const float wa = w[k] * ab.x, wb = w[k] * ab.y;
+                a0 += wa; a1 += wb; a2 = fmaf(wa, ab.x, a2); a3 = fmaf(wb, ab.y, a3); a4 = fmaf(wa, ab.y, a4);
+            }
+            h[J][0] = a0; h[J][1] = a1; h[J][2] = a2; h[J][3] = a3; h[J][4] = a4;
+        }
+        // ---- first stage, vertical: rows i-10 .. i are in slots J+1 .. J+11 (mod 11) -> the filtered maps at row s = i - 5
+        {
+            float mu1 = 0.f, mu2 = 0.f, ea = 0.f, ec = 0.f, eb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int sl = (J + 1 + k) % 11;
+                mu1 = fmaf(w[k], h[sl][0], mu1); mu2 = fmaf(w[k], h[sl][1], mu2); ea = fmaf(w[k], h[sl][2], ea);
+                ec = fmaf(w[k], h[sl][3], ec); eb = fmaf(w[k], h[sl][4], eb);
+            }
+            const int srow = i - kR;
+            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            if (col1 && srow >= 0 && srow < P.H) {
+                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s11 = ea - mu1s, s22 = ec - mu2s, s12 = eb - mu12;
+                const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
+                const float inv = 1.f / (B1 * B2);
+                const float S = A1 * A2 * inv;
+                // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
+                d1 = g * ((2.f * mu2 * (A2 - A1)) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2));
+                d2 = g * (-S / B2);
+                d3 = g * (2.f * A1 * inv);
+                if (own1 && srow >= y0 && srow < y1) sum_s += S;
+            }
+            s_d[buf][0][tid] = d1; s_d[buf][1][tid] = d2; s_d[buf][2][tid] = d3;
+        }
+        // ---- second stage on the adjoint row written ONE iteration ago (made visible by this iteration's barrier)
+        {
+            const int pb = buf ^ 1;
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                q0 = fmaf(w[k], s_d[pb][0][tid + k < kFT ? tid + k : kFT - 1], q0);
+                q1 = fmaf(w[k], s_d[pb][1][tid + k < kFT ? tid + k : kFT - 1], q1);
+                q2 = fmaf(w[k], s_d[pb][2][tid + k < kFT ? tid + k : kFT - 1], q2);
+            }
+            constexpr int J2 = (J + 10) % 11;            // the adjoint row of the previous iteration sits one slot back
+            hd[J2][0] = q0; hd[J2][1] = q1; hd[J2][2] = q2;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const int sl = (J2 + 1 + k) % 11;
+                r0 = fmaf(w[k], hd[sl][0], r0); r1 = fmaf(w[k], hd[sl][1], r1); r2 = fmaf(w[k], hd[sl][2], r2);
+            }
+            if (emit) {
+                const float x = em * o_im + cc, y = o_gt;
+                const float d = x - y;
+                sum_l1 += fabsf(d);
+                const float gl1 = l1w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                const float gg = r0 + 2.f * x * r1 + y * r2 + gl1;                   // dL/dx'
+                P.dL_dim[(size_t)vc * HW + (size_t)o_row * P.W + gx2] = em * gg;
+                sum_gm += gg * (em * o_im);                                          // d x'/d cam_m = exp(cam_m) * im
+                sum_gc += gg;
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            s_v4[r0 + j][col] = make_float4(sx[j], sy[j], sxx[j], syy[j]);
-            s_v1[r0 + j][col] = sxy[j];
-        }
+    };
+    for (int base = i_first; base <= i_last; base += 11) {
+        if (base + 0 <= i_last) row(base + 0, IC<0>()); if (base + 1 <= i_last) row(base + 1, IC<1>());
+        if (base + 2 <= i_last) row(base + 2, IC<2>()); if (base + 3 <= i_last) row(base + 3, IC<3>());
+        if (base + 4 <= i_last) row(base + 4, IC<4>()); if (base + 5 <= i_last) row(base + 5, IC<5>());
+        if (base + 6 <= i_last) row(base + 6, IC<6>()); if (base + 7 <= i_last) row(base + 7, IC<7>());
+        if (base + 8 <= i_last) row(base + 8, IC<8>()); if (base + 9 <= i_last) row(base + 9, IC<9>());
+        if (base + 10 <= i_last) row(base + 10, IC<10>());
     }
-    __syncthreads();
-    // horizontal pass: lane -> row (fastest), 4 consecutive output columns per thread
-    const int row = tid & 15, c0 = (tid >> 4) * 4;
-    const bool hrun = c0 < kTW;                          // (kTW / 4) * 16 threads take part in the horizontal pass
-    float mu1[4] = { 0, 0, 0, 0 }, mu2[4] = { 0, 0, 0, 0 }, ea[4] = { 0, 0, 0, 0 }, ec[4] = { 0, 0, 0, 0 }, eb[4] = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int k = 0; k < 14; k++) {
-        const float4 h4 = hrun ? s_v4[row][c0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float h1 = hrun ? s_v1[row][c0 + k] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int tap = k - j;
-            if (tap >= 0 && tap < 11) {
-                const float w = P.win[tap];
-                mu1[j] += w * h4.x; mu2[j] += w * h4.y; ea[j] += w * h4.z; ec[j] += w * h4.w; eb[j] += w * h1;
-            }
-        }
-    }
-    const int py = y0 + row;
-    const float N = 3.f * (float)HW;
-    const float g = -0.2f * (P.weight ? P.weight[v] : 1.f) / N;              // dL/dS
-    float l1 = 0.f, ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int px = x0 + c0 + j;
-        if (hrun && px < P.W && py < P.H) {
-            const float mu1s = mu1[j] * mu1[j], mu2s = mu2[j] * mu2[j], mu12 = mu1[j] * mu2[j];
-            const float s11 = ea[j] - mu1s, s22 = ec[j] - mu2s, s12 = eb[j] - mu12;
-            const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
-            const float inv = 1.f / (B1 * B2);
-            const float S = A1 * A2 * inv;
-            ss += S;
-            const float2 ab = s_in[row + kR][c0 + j + kR];
-            l1 += fabsf(ab.x - ab.y);
-            // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
-            const float dS_dmu1 = (2.f * mu2[j] * (A2 - A1)) * inv - S * (2.f * mu1[j] / B1 - 2.f * mu1[j] / B2);
-            const float dS_da = -S / B2;
-            const float dS_db = 2.f * A1 * inv;
-            P.D[(size_t)vc * HW + (size_t)py * P.W + px] = make_float4(g * dS_dmu1, g * dS_da, g * dS_db, 0.f);
-        }
-    }
-    const float tl1 = block_sum(l1, s_red);
-    const float tss = block_sum(ss, s_red);
+    const float tl1 = block_sum(sum_l1, s_red), tss = block_sum(sum_s, s_red);
+    const float tgm = block_sum(sum_gm, s_red), tgc = block_sum(sum_gc, s_red);
     if (tid == 0) {
         const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
         P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_photo_grad(const PhP P)
-{
-    __shared__ float4 s_d[kIH][kIW + 1];                 // (D1, D2, D3, -) with halo
-    __shared__ float4 s_v[kTH][kPitch];                  // vertically filtered
-    __shared__ float s_red[4];
-    const int tid = threadIdx.x;
-    const int vc = blockIdx.z, v = vc / 3;
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
-    const size_t HW = (size_t)P.H * P.W;
-    const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
-    for (int i = tid; i < kIH * kIW; i += kBlock) {
-        const int r = i / kIW, c = i - r * kIW;
-        const int yy = y0 + r - kR, xx = x0 + c - kR;
-        const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
-        s_d[r][c] = in ? P.D[(size_t)vc * HW + (size_t)yy * P.W + xx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    for (int t = tid; t < kIW * (kTH / 4); t += kBlock) {
-        const int run = t / kIW, col = t - run * kIW, r0 = run * 4;
-        float a0[4] = { 0, 0, 0, 0 }, a1[4] = { 0, 0, 0, 0 }, a2[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-            const float4 d4 = s_d[r0 + k][col];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int tap = k - j;
-                if (tap >= 0 && tap < 11) {
-                    const float w = P.win[tap];
-                    a0[j] += w * d4.x; a1[j] += w * d4.y; a2[j] += w * d4.z;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) s_v[r0 + j][col] = make_float4(a0[j], a1[j], a2[j], 0.f);
-    }
-    __syncthreads();
-    const int row = tid & 15, c0 = (tid >> 4) * 4;
-    const bool hrun = c0 < kTW;
-    float q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 }, q2[4] = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int k = 0; k < 14; k++) {
-        const float4 h4 = hrun ? s_v[row][c0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int tap = k - j;
-            if (tap >= 0 && tap < 11) {
-                const float w = P.win[tap];
-                q0[j] += w * h4.x; q1[j] += w * h4.y; q2[j] += w * h4.z;
-            }
-        }
-    }
-    const int py = y0 + row;
-    const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
-    float gm = 0.f, gc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int px = x0 + c0 + j;
-        if (hrun && px < P.W && py < P.H) {
-            const size_t o = (size_t)vc * HW + (size_t)py * P.W + px;
-            const float imv = P.im[o], y = P.gt[o];
-            const float x = em * imv + cc;
-            const float d = x - y;
-            const float gl1 = 0.8f * wv / N * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-            const float g = q0[j] + 2.f * x * q1[j] + y * q2[j] + gl1;         // dL/dx'
-            P.dL_dim[o] = em * g;
-            gm += g * (em * imv);                                               // d x'/d cam_m = exp(cam_m) * im
-            gc += g;
-        }
-    }
-    const float tgm = block_sum(gm, s_red);
-    const float tgc = block_sum(gc, s_red);
-    if (tid == 0) {
-        const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
         P.part_cam[2 * t] = tgm; P.part_cam[2 * t + 1] = tgc;
     }
 }
@@ -355,12 +345,25 @@ T4D_EXPORT int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const f
     return T4D_OK;
 }
 
+// strips and row segments of the fused kernel for an H x W image: strips as even as possible below 118 columns; segments of 64
+// rows for small workloads (more workgroups), 128 rows from a million pixels per batch on (20 warm-up rows each)
+static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty, int *tw, int *th)
+{
+    *tx = (W + kFTW - 1) / kFTW;
+    *tw = (W + *tx - 1) / *tx;
+    const long long work = (long long)n_views * 3 * H * W;
+    *th = work >= (1ll << 25) ? 128 : 64;
+    if (*th > H) *th = H;
+    *ty = (H + *th - 1) / *th;
+}
+
 T4D_EXPORT size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int32_t W)
 {
     if (n_views < 1 || H < 1 || W < 1) return 0;
-    const size_t n = (size_t)n_views * 3 * H * W;
-    const size_t tiles = (size_t)((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) * n_views * 3;
-    return align_up(n * 16) + 2 * align_up(tiles * 8);
+    int tx, ty, tw, th;
+    photo_tiling(n_views, H, W, &tx, &ty, &tw, &th);
+    const size_t tiles = (size_t)tx * ty * n_views * 3;
+    return 2 * align_up(tiles * 8);
 }
 
 T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *cam_m,
@@ -377,22 +380,20 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     PhP P;
     memset(&P, 0, sizeof(P));
     P.V = n_views; P.H = H; P.W = W;
-    P.tx = (W + kTW - 1) / kTW; P.ty = (H + kTH - 1) / kTH;
+    photo_tiling(n_views, H, W, &P.tx, &P.ty, &P.tw, &P.th);
+    if (P.ty > 65535) return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: image too tall%s", "");
     P.im = im; P.gt = gt; P.cam_m = cam_m; P.cam_c = cam_c; P.weight = view_weight;
     P.loss = loss; P.dL_dim = dL_dim; P.dL_dm = dL_dcam_m; P.dL_dc = dL_dcam_c;
-    const size_t n = (size_t)n_views * 3 * H * W, tiles = (size_t)P.tx * P.ty * n_views * 3;
+    const size_t tiles = (size_t)P.tx * P.ty * n_views * 3;
     char *sc = (char *)scratch;
-    P.D = (float4 *)sc;
-    P.part_loss = (float *)(sc + align_up(n * 16));
-    P.part_cam = (float *)(sc + align_up(n * 16) + align_up(tiles * 8));
+    P.part_loss = (float *)sc;
+    P.part_cam = (float *)(sc + align_up(tiles * 8));
     // the reference's window: exp(-(i-5)^2 / (2*1.5^2)) for i = 0..10, as float32, normalised in float32 (external.py:73-76)
     float g[11], sum = 0.f;
     for (int i = 0; i < 11; i++) { g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
     for (int i = 0; i < 11; i++) P.win[i] = g[i] / sum;
     hipStream_t stream = (hipStream_t)hip_stream;
-    const dim3 grid(P.tx, P.ty, n_views * 3);
-    hipLaunchKernelGGL(k_photo_stats, grid, dim3(kBlock), 0, stream, P);
-    hipLaunchKernelGGL(k_photo_grad, grid, dim3(kBlock), 0, stream, P);
+    hipLaunchKernelGGL(k_photo_fused, dim3(P.tx, P.ty, n_views * 3), dim3(kFT), 0, stream, P);
     hipLaunchKernelGGL(k_photo_final, dim3(n_views), dim3(kBlock), 0, stream, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_photometric_loss launch: %s", hipGetErrorString(e));

@@ -18,7 +18,7 @@ csrc/t4d_raster.hip behind include/topo4d_raster.h.  There is no CPU path: CPU t
 from __future__ import annotations
 
 import ctypes as C
-from collections import OrderedDict
+from collections import OrderedDict, deque
 from typing import List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
@@ -50,6 +50,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # sync policy and pair-arena capacity
 # ------------------------------------------------------------------------------------------------------------
 _SYNC_MODE = "checked"
+_SYNC_MODE_EXPLICIT = False     # set_sync_mode() was called: until then the one-view drop-in (GaussianRasterizer) runs "auto"
 _CAPACITY = {}          # (device_index, P, H, W) -> learned per-view pair capacity
 _LONGEST_BIN = {}       # (device_index, P, H, W) -> longest tile list a checked forward has reported for this scene size
 _AUTO = {}              # (device_index, P, H, W, views key) -> _AutoTrack of the "auto" sync mode
@@ -59,50 +60,44 @@ _BATCH_LOG = None       # when a list: every ViewBatch that runs a forward is ap
 
 
 class _AutoTrack:
-    """Bookkeeping of the "auto" sync mode for one (scene size, camera set): a ring of pinned status blocks, one per
-    un-synchronised forward still in flight, each with the event that says it has landed, and the largest need seen."""
+    """Bookkeeping of the "auto" sync mode for one (scene size, camera set): a ring of 16-byte status blocks in pinned host
+    memory, one per un-synchronised forward still in flight, and the largest need seen.  A slot is filled with an impossible
+    value before its forward is enqueued; the forward's asynchronous device-to-host copy overwrites it, so "has it landed?"
+    is two host loads - no event, no stream object on the per-iteration path."""
     RING = 8
-    __slots__ = ("pinned", "host", "events", "caps", "head", "count", "need", "key")
+    __slots__ = ("pinned", "host", "args", "head", "count", "need", "key")
 
     def __init__(self, key=None):
         self.key = key                                  # (device_index, P, H, W) whose capacity this track feeds
         self.pinned = torch.zeros(self.RING, 2, dtype=torch.int64).pin_memory()
         self.host = self.pinned.numpy()                 # same memory, cheap scalar reads
-        self.events = [torch.cuda.Event() for _ in range(self.RING)]
-        self.caps = [0] * self.RING
+        base = self.pinned.data_ptr()
+        self.args = [C.cast(C.c_void_p(base + 16 * i), C.POINTER(T4DStatus)) for i in range(self.RING)]
         self.head = 0                                   # next slot to hand out
-        self.count = 0                                  # slots in flight (oldest = head - count)
+        self.count = 0                                  # slots in flight
         self.need = 0
 
-    def slot_ptr(self) -> int:
-        return self.pinned.data_ptr() + 16 * self.head
-
-    def mark(self, stream, cap):
-        self.events[self.head].record(stream)
-        self.caps[self.head] = cap
-        self.head = (self.head + 1) % self.RING
-        self.count += 1
-        _INFLIGHT[id(self)] = self
-
-    def harvest(self):
-        """Yields (overflow, need, capacity used) of every un-synchronised call whose status has landed, oldest first.
-        Waits for the oldest one only when the ring is full (the host is then RING forwards ahead of the GPU)."""
-        out = []
-        while self.count:
-            tail = (self.head - self.count) % self.RING
+    def claim(self, cap: int):
+        """Reserves the next slot for a forward that is about to be enqueued; returns the status pointer to pass to it."""
+        if self.count == self.RING:                     # the host is RING forwards of this camera set ahead of the GPU
+            poll_truncation()
             if self.count == self.RING:
-                self.events[tail].synchronize()
-            elif not self.events[tail].query():
-                break
-            raw = int(self.host[tail, 0])
-            out.append((raw & 0xffffffff, (raw >> 32) & 0xffffffff, self.caps[tail]))
-            self.count -= 1
-        if not self.count:
-            _INFLIGHT.pop(id(self), None)
-        return out
+                torch.cuda.synchronize()
+                poll_truncation()
+                if self.count == self.RING:             # statuses that can never land (their forward failed): forget them
+                    for e in [e for e in _PENDING if e[0] is self]:
+                        _PENDING.remove(e)
+                    self.count = 0
+        i = self.head
+        self.host[i, 0] = -1
+        self.host[i, 1] = -1
+        self.head = (i + 1) % self.RING
+        self.count += 1
+        _PENDING.append((self, i, cap))
+        return self.args[i]
 
 
-_INFLIGHT = {}          # id(track) -> _AutoTrack with un-harvested status blocks
+_PENDING = deque()      # (track, slot, capacity used) of the un-synchronised forwards, in submission order
 
 
 def poll_truncation() -> None:
@@ -110,15 +105,21 @@ def poll_truncation() -> None:
     the one being rendered - grow the arenas they ask for, and raise RuntimeError if any of those forwards was truncated
     (its backward returned zero gradients, see t4d_rasterize_backward).  Every auto-mode forward calls this first; an
     optimisation loop may also call it right before `optimizer.step()` to learn about a truncated pass as early as the GPU
-    allows.  Never synchronises unless a track's ring is full."""
+    allows.  Never synchronises: statuses are inspected in submission order, the first one still in flight ends the look."""
     truncated = None
-    for track in list(_INFLIGHT.values()):
-        for overflow, need, cap_used in track.harvest():
-            track.need = max(track.need, need)
-            if overflow:
-                truncated = (need, cap_used)
-                if track.key is not None:
-                    _CAPACITY[track.key] = max(_CAPACITY.get(track.key, 0), _round_capacity(track.need))
+    while _PENDING:
+        track, i, cap_used = _PENDING[0]
+        raw0, raw1 = int(track.host[i, 0]), int(track.host[i, 1])
+        if raw0 == -1 or raw1 == -1:                    # (both halves: a copy caught half-way reads as "not yet")
+            break
+        _PENDING.popleft()
+        track.count -= 1
+        overflow, need = raw0 & 0xffffffff, (raw0 >> 32) & 0xffffffff
+        track.need = max(track.need, need)
+        if overflow:
+            truncated = (need, cap_used)
+            if track.key is not None:
+                _CAPACITY[track.key] = max(_CAPACITY.get(track.key, 0), _round_capacity(track.need))
     if truncated is not None:
         raise RuntimeError(
             f"topo4d_amd (sync_mode='auto'): an earlier render needed {truncated[0]} (Gaussian,tile) pairs per view but its "
@@ -127,7 +128,10 @@ def poll_truncation() -> None:
 
 
 def set_sync_mode(mode: str) -> None:
-    """"checked" (default): the forward synchronises once, after the binning sizes are known, and re-runs
+    """Without a call of this function `ViewBatch` / `rasterize_views` run "checked" and the one-view drop-in
+    `GaussianRasterizer` - Topo4D's optimisation loop, one camera per call thousands of times per frame (train.py:661-673) -
+    runs "auto" (a `debug=True` camera is always checked).  After a call everything runs the mode it names.
+    "checked": the forward synchronises once, after the binning sizes are known, and re-runs
     with a larger pair arena if it was too small — exactly where upstream reads `num_rendered` back.
     "lazy": never synchronises; tile lists are truncated (memory-safe) if the arena learned by earlier checked
     calls is too small, and `ViewBatch.fetch_status()` / `last_status()` reports it.  Use lazy only when the
@@ -139,10 +143,11 @@ def set_sync_mode(mode: str) -> None:
     consecutive iterations of an optimiser cannot overflow it; should a previous call nevertheless have been truncated
     (the scene jumped by more than a third between two calls), its backward returned zero gradients and a RuntimeError
     says so at the next forward (or at an explicit `poll_truncation()` before `optimizer.step()`)."""
-    global _SYNC_MODE
+    global _SYNC_MODE, _SYNC_MODE_EXPLICIT
     if mode not in ("checked", "lazy", "auto"):
         raise ValueError("sync mode must be 'checked', 'lazy' or 'auto'")
     _SYNC_MODE = mode
+    _SYNC_MODE_EXPLICIT = True
 
 
 def get_sync_mode() -> str:
@@ -184,10 +189,11 @@ def pack_views(settings: Sequence[GaussianRasterizationSettings], device) -> tor
     recs = []
     for s in settings:
         key = id(s)
-        ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, str(device))
+        ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, device)
         hit = _VIEW_CACHE.get(key)
         if hit is not None and hit[0] is s and hit[1] == ver:
-            _VIEW_CACHE.move_to_end(key)
+            if len(settings) > 1:
+                _VIEW_CACHE.move_to_end(key)             # (one camera per call: the LRU order is refreshed on misses only)
             recs.append(hit[2])
             continue
         rec = _pack_one_view(s, device)
@@ -241,6 +247,26 @@ def _raw_stream(device) -> int:
         return torch.cuda.current_stream(device).cuda_stream
 
 
+class _Plan:
+    """Per (device, V, P, H, W, M, degree, scale modifier, flags) scratch of the host side: the ctypes structures of one call
+    are built once and refilled (a call only uses them while the C function runs), and the byte sizes the library reports for
+    a given pair capacity are remembered - Topo4D calls the rasterizer thousands of times per frame with the same shapes."""
+    __slots__ = ("fio", "bio", "status", "state_bytes", "scratch_bytes", "fio_ref", "bio_ref", "status_ref")
+
+    def __init__(self):
+        self.fio, self.bio, self.status = T4DForwardIO(), T4DBackwardIO(), T4DStatus()
+        self.fio_ref, self.bio_ref, self.status_ref = C.byref(self.fio), C.byref(self.bio), C.byref(self.status)
+        self.state_bytes, self.scratch_bytes = {}, {}
+
+
+_PLANS = {}
+_F32 = torch.float32
+
+
+def _dp(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
 class ViewBatch:
     """One forward (+ optional backward) of V views of the same Gaussians through the C ABI.
 
@@ -249,11 +275,11 @@ class ViewBatch:
     """
 
     def __init__(self, views: torch.Tensor, H: int, W: int, scale_modifier: float = 1.0, sh_degree: int = 0,
-                 debug: bool = False, prefiltered: bool = False, cam_key=None):
+                 debug: bool = False, prefiltered: bool = False, cam_key=None, sync_mode: Optional[str] = None):
         if not views.is_cuda:
             raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
         self.lib = _lib.load()
-        self.views = views.contiguous()
+        self.views = views if views.is_contiguous() else views.contiguous()
         self.V = int(views.shape[0])
         self.H, self.W = int(H), int(W)
         self.scale_modifier = float(scale_modifier)
@@ -262,13 +288,16 @@ class ViewBatch:
         self.prefiltered = bool(prefiltered)
         self.device = views.device
         self.cam_key = cam_key if cam_key is not None else (views.data_ptr(), self.V)   # identity of the camera set ("auto" mode)
+        self.sync_mode = sync_mode                      # None: the module-wide mode at the time of the forward
         self.state = None
         self.prob = None
         self.inputs = None
         self.radii = None
+        self.plan = None
+        self.flat_grads = False                         # True (autograd path, V = 1): gradients come back without the view axis
 
     # -- helpers ---------------------------------------------------------------------------------------------
-    def _problem(self, P: int, M: int, cap: int, checked: bool) -> T4DProblem:
+    def _flags(self, P: int, checked: bool) -> int:
         flags = 0
         if checked:
             flags |= T4D_FLAG_CHECKED
@@ -281,11 +310,10 @@ class ViewBatch:
         longest = _LONGEST_BIN.get((self.device.index, P, self.H, self.W))
         if longest is not None and longest <= 1536:
             flags |= T4D_FLAG_NO_LONG_BINS
-        return T4DProblem(T4D_ABI_VERSION, self.V, P, self.H, self.W, self.sh_degree, M, self.scale_modifier,
-                          cap, flags, 0)
+        return flags
 
     def _stream(self):
-        return C.c_void_p(_raw_stream(self.device))
+        return _raw_stream(self.device)
 
     # -- forward ---------------------------------------------------------------------------------------------
     def forward(self, means3D, opacities, scales=None, rotations=None, colors_precomp=None, shs=None,
@@ -316,18 +344,29 @@ class ViewBatch:
             if M < (self.sh_degree + 1) ** 2:
                 raise ValueError("shs holds fewer coefficients than sh_degree needs")
         V, H, W = self.V, self.H, self.W
-        color = torch.empty(V, 3, H, W, dtype=torch.float32, device=dev)
-        depth = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
-        alpha = torch.empty(V, 1, H, W, dtype=torch.float32, device=dev)
-        radii = torch.empty(V, P, dtype=torch.int32, device=dev)
+        if self.flat_grads:                       # the drop-in's own shapes (train.py:307): no view axis to strip afterwards
+            color = torch.empty((3, H, W), dtype=_F32, device=dev)
+            depth = torch.empty((1, H, W), dtype=_F32, device=dev)
+            alpha = torch.empty((1, H, W), dtype=_F32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        else:
+            color = torch.empty((V, 3, H, W), dtype=_F32, device=dev)
+            depth = torch.empty((V, 1, H, W), dtype=_F32, device=dev)
+            alpha = torch.empty((V, 1, H, W), dtype=_F32, device=dev)
+            radii = torch.empty((V, P), dtype=torch.int32, device=dev)
 
+        mode = self.sync_mode or _SYNC_MODE
         key = (dev.index, P, H, W)
-        cap = _CAPACITY.get(key, _initial_capacity(P))
-        checked = (_SYNC_MODE == "checked") or self.debug or key not in _CAPACITY
+        cap = _CAPACITY.get(key)
+        known = cap is not None
+        if not known:
+            cap = _initial_capacity(P)
+        checked = (mode == "checked") or self.debug or not known
         track = None
-        if _SYNC_MODE == "auto" and not self.debug:
-            poll_truncation()                                     # statuses of every camera set that have landed by now
-            cap = _CAPACITY.get(key, cap)
+        if mode == "auto" and not self.debug:
+            if _PENDING:
+                poll_truncation()                                 # statuses of every camera set that have landed by now
+                cap = _CAPACITY.get(key, cap)
             akey = key + (self.cam_key,)
             track = _AUTO.get(akey)
             if track is None:
@@ -341,19 +380,32 @@ class ViewBatch:
                     cap = _round_capacity(track.need)
                     _CAPACITY[key] = max(_CAPACITY.get(key, 0), cap)
                 cap = _CAPACITY.get(key, cap)
-        status = T4DStatus()
+        pkey = (dev.index, V, P, H, W, M, self.sh_degree, self.scale_modifier)
+        plan = _PLANS.get(pkey)
+        if plan is None:
+            plan = _PLANS[pkey] = _Plan()
+        self.plan = plan
+        status = plan.status
+        lib = self.lib
+        stream = _raw_stream(dev)
         for _attempt in range(6):
-            prob = self._problem(P, M, cap, checked)
-            status_arg = C.byref(status)
+            flags = self._flags(P, checked)
+            status_arg = plan.status_ref
             if track is not None and not checked:
-                prob.flags |= _lib.T4D_FLAG_ASYNC_STATUS
-                status_arg = C.cast(C.c_void_p(track.slot_ptr()), C.POINTER(T4DStatus))
-            nbytes = self.lib.t4d_state_bytes(C.byref(prob))
-            state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            io = T4DForwardIO(_ptr(self.views), _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations),
-                              _ptr(cov3D_precomp), _ptr(colors_precomp), _ptr(shs), _ptr(color), _ptr(depth),
-                              _ptr(alpha), _ptr(radii), _ptr(state), nbytes)
-            rc = self.lib.t4d_rasterize_forward(C.byref(prob), C.byref(io), status_arg, self._stream())
+                flags |= _lib.T4D_FLAG_ASYNC_STATUS
+                status_arg = track.claim(cap)
+            prob = T4DProblem(T4D_ABI_VERSION, V, P, H, W, self.sh_degree, M, self.scale_modifier, cap, flags, 0)
+            nbytes = plan.state_bytes.get(cap)
+            if nbytes is None:
+                nbytes = plan.state_bytes[cap] = lib.t4d_state_bytes(C.byref(prob))
+            state = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            io = plan.fio
+            io.views = self.views.data_ptr(); io.means3D = means3D.data_ptr(); io.opacities = opacities.data_ptr()
+            io.scales = _dp(scales); io.rotations = _dp(rotations); io.cov3D_precomp = _dp(cov3D_precomp)
+            io.colors_precomp = _dp(colors_precomp); io.shs = _dp(shs)
+            io.out_color = color.data_ptr(); io.out_depth = depth.data_ptr(); io.out_alpha = alpha.data_ptr()
+            io.out_radii = radii.data_ptr(); io.state = state.data_ptr(); io.state_bytes = nbytes
+            rc = lib.t4d_rasterize_forward(C.byref(prob), plan.fio_ref, status_arg, stream)
             if rc == T4D_OK:
                 break
             if rc == T4D_ERR_PAIR_OVERFLOW:
@@ -369,13 +421,14 @@ class ViewBatch:
             _LONGEST_BIN[key] = max(_LONGEST_BIN.get(key, 0), int(status.max_tile_pairs))
             if track is not None:
                 track.need = max(track.need, int(status.max_pairs_per_view))
-        elif track is not None:
-            track.mark(torch.cuda.current_stream(dev), cap)
+            st = T4DStatus(status.max_pairs_per_view, status.total_pairs, status.overflow, status.max_tile_pairs)
+            self.last_status = st
+        else:
+            self.last_status = None
         self.prob, self.state, self.radii = prob, state, radii
         if _BATCH_LOG is not None:
             _BATCH_LOG.append(self)
         self.inputs = (means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs)
-        self.last_status = status if checked else None
         return color, radii, depth, alpha
 
     # -- backward --------------------------------------------------------------------------------------------
@@ -385,7 +438,7 @@ class ViewBatch:
         <color, dL_dcolor> + <depth, dL_ddepth> + <alpha, dL_dalpha> per view (a by-product of the replay)."""
         if self.state is None:
             raise RuntimeError("backward() before forward()")
-        if self.inputs is None or self.inputs[0] is None:
+        if self.inputs is None:
             raise RuntimeError("this ViewBatch's inputs are owned by an autograd graph (GaussianRasterizer / rasterize_views): "
                                "call .backward() on the loss instead of ViewBatch.backward()")
         dev = self.device
@@ -402,23 +455,31 @@ class ViewBatch:
             raise ValueError("cotangent_dot must be a contiguous fp32 [V] tensor on the rasterizer's device")
         # separate allocations on purpose: autograd's AccumulateGrad only adopts a gradient without copying it when the
         # tensor owns its storage (carving them out of one buffer cost six clone kernels per backward)
-        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        g = dict(means3D=new(V, P, 3), means2D=new(V, P, 3), opacities=new(V, P, 1))
-        g["colors_precomp"] = new(V, P, 3) if colors_precomp is not None else None
-        g["shs"] = new(V, P, M, 3) if shs is not None else None
-        g["scales"] = new(V, P, 3) if cov3D_precomp is None else None
-        g["rotations"] = new(V, P, 4) if cov3D_precomp is None else None
-        g["cov3D_precomp"] = new(V, P, 6) if cov3D_precomp is not None else None
-        prob = self.prob
-        sbytes = self.lib.t4d_backward_scratch_bytes(C.byref(prob))
-        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-        io = T4DBackwardIO(_ptr(self.views), _ptr(means3D), _ptr(opacities), _ptr(scales), _ptr(rotations),
-                           _ptr(cov3D_precomp), _ptr(colors_precomp), _ptr(shs), _ptr(self.radii),
-                           _ptr(self.state), self.state.numel(), _ptr(dL_dcolor), _ptr(dL_ddepth), _ptr(dL_dalpha),
-                           _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["colors_precomp"]), _ptr(g["shs"]),
-                           _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]),
-                           _ptr(scratch), sbytes, _ptr(cotangent_dot))
-        rc = self.lib.t4d_rasterize_backward(C.byref(prob), C.byref(io), self._stream())
+        lead = () if self.flat_grads else (V,)
+        new = lambda *shape: torch.empty(lead + shape, dtype=_F32, device=dev)
+        g = dict(means3D=new(P, 3), means2D=new(P, 3), opacities=new(P, 1))
+        g["colors_precomp"] = new(P, 3) if colors_precomp is not None else None
+        g["shs"] = new(P, M, 3) if shs is not None else None
+        g["scales"] = new(P, 3) if cov3D_precomp is None else None
+        g["rotations"] = new(P, 4) if cov3D_precomp is None else None
+        g["cov3D_precomp"] = new(P, 6) if cov3D_precomp is not None else None
+        prob, plan, lib = self.prob, self.plan, self.lib
+        cap = prob.pair_capacity
+        sbytes = plan.scratch_bytes.get(cap)
+        if sbytes is None:
+            sbytes = plan.scratch_bytes[cap] = lib.t4d_backward_scratch_bytes(C.byref(prob))
+        scratch = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+        io = plan.bio
+        io.views = self.views.data_ptr(); io.means3D = means3D.data_ptr(); io.opacities = opacities.data_ptr()
+        io.scales = _dp(scales); io.rotations = _dp(rotations); io.cov3D_precomp = _dp(cov3D_precomp)
+        io.colors_precomp = _dp(colors_precomp); io.shs = _dp(shs)
+        io.radii = self.radii.data_ptr(); io.state = self.state.data_ptr(); io.state_bytes = self.state.numel()
+        io.dL_dcolor = dL_dcolor.data_ptr(); io.dL_ddepth = _dp(dL_ddepth); io.dL_dalpha = _dp(dL_dalpha)
+        io.dL_dmeans3D = g["means3D"].data_ptr(); io.dL_dmeans2D = g["means2D"].data_ptr()
+        io.dL_dcolors = _dp(g["colors_precomp"]); io.dL_dshs = _dp(g["shs"]); io.dL_dopacities = g["opacities"].data_ptr()
+        io.dL_dscales = _dp(g["scales"]); io.dL_drotations = _dp(g["rotations"]); io.dL_dcov3D = _dp(g["cov3D_precomp"])
+        io.scratch = scratch.data_ptr(); io.scratch_bytes = sbytes; io.cotangent_dot = _dp(cotangent_dot)
+        rc = lib.t4d_rasterize_backward(C.byref(prob), plan.bio_ref, _raw_stream(dev))
         if rc != T4D_OK:
             raise RuntimeError(f"t4d_rasterize_backward failed (code {rc}): {_lib.last_error()}")
         self._keepalive = (scratch, dL_dcolor, dL_ddepth, dL_dalpha)
@@ -454,22 +515,31 @@ def view_dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = Non
 # ------------------------------------------------------------------------------------------------------------
 # autograd glue
 # ------------------------------------------------------------------------------------------------------------
+class _CallSpec:
+    """Everything of a render call that is not a differentiable tensor, as ONE autograd-invisible argument."""
+    __slots__ = ("views", "H", "W", "scale_modifier", "sh_degree", "debug", "prefiltered", "cam_key", "sync_mode", "one_view")
+
+    def __init__(self, views, H, W, scale_modifier, sh_degree, debug, prefiltered, cam_key, sync_mode=None, one_view=False):
+        self.views, self.H, self.W, self.scale_modifier, self.sh_degree = views, H, W, scale_modifier, sh_degree
+        self.debug, self.prefiltered, self.cam_key, self.sync_mode, self.one_view = debug, prefiltered, cam_key, sync_mode, one_view
+
+
 class _RasterizeViews(torch.autograd.Function):
-    """Inputs in upstream's order; outputs (color[V,3,H,W], radii[V,P], depth[V,1,H,W], alpha[V,1,H,W])."""
+    """Inputs in upstream's order (None where upstream passes an empty tensor) + the call's _CallSpec; outputs
+    (color[V,3,H,W], radii[V,P], depth[V,1,H,W], alpha[V,1,H,W]), or without the view axis for the one-view drop-in."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                views, H, W, scale_modifier, sh_degree, debug, prefiltered, cam_key=None):
-        batch = ViewBatch(views, H, W, scale_modifier, sh_degree, debug, prefiltered, cam_key)
-        none_if_empty = lambda t: None if (t is None or t.numel() == 0) else t
-        color, radii, depth, alpha = batch.forward(
-            means3D, opacities, none_if_empty(scales), none_if_empty(rotations), none_if_empty(colors_precomp),
-            none_if_empty(sh), none_if_empty(cov3Ds_precomp))
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, spec):
+        batch = ViewBatch(spec.views, spec.H, spec.W, spec.scale_modifier, spec.sh_degree, spec.debug, spec.prefiltered,
+                          spec.cam_key, spec.sync_mode)
+        batch.flat_grads = spec.one_view
+        color, radii, depth, alpha = batch.forward(means3D, opacities, scales, rotations, colors_precomp, sh, cov3Ds_precomp)
         ctx.batch = batch
         # the backward kernels re-read the forward inputs: saving them through autograd (as upstream does) makes an in-place
         # update between forward and backward raise instead of silently differentiating at the wrong point
-        ctx.input_slots = [i for i, t in enumerate(batch.inputs) if t is not None]
-        ctx.save_for_backward(*[batch.inputs[i] for i in ctx.input_slots])
+        inputs = batch.inputs
+        ctx.input_slots = slots = [i for i in range(7) if inputs[i] is not None]
+        ctx.save_for_backward(*[inputs[i] for i in slots])
         batch.inputs = None                  # ownership moved to the ctx (a direct ViewBatch.backward() now raises clearly)
         ctx.set_materialize_grads(False)     # unused depth/alpha outputs arrive as None -> cheaper backward kernel
         ctx.mark_non_differentiable(radii)
@@ -482,30 +552,29 @@ class _RasterizeViews(torch.autograd.Function):
         inputs = [None] * 7
         for slot, t in zip(ctx.input_slots, ctx.saved_tensors):         # raises if one of them was modified in place
             inputs[slot] = t
-        batch.inputs = tuple(inputs)
+        batch.inputs = inputs
         if grad_color is None:
             grad_color = torch.zeros(batch.V, 3, batch.H, batch.W, dtype=torch.float32, device=batch.device)
         g = batch.backward(grad_color, grad_depth, grad_alpha)
         batch.inputs = None                  # the batch (kept by GraphedViews / _BATCH_LOG) must not keep the inputs alive
+        ctx.batch = None
+        shp3, shp2, shpo = ctx.shapes
+        if batch.flat_grads:                 # one view: the kernel's outputs already have the inputs' shapes
+            d2 = g["means2D"] if (shp2 is not None and ctx.needs_input_grad[1]) else None
+            go = g["opacities"]
+            return (g["means3D"], d2, g["shs"], g["colors_precomp"], go if go.shape == shpo else go.reshape(shpo),
+                    g["scales"], g["rotations"], g["cov3D_precomp"], None)
         red = (lambda t: None if t is None else t.sum(0)) if batch.V > 1 else \
               (lambda t: None if t is None else t[0])
-        shp3, shp2, shpo = ctx.shapes
         d_means2D = None
         if shp2 is not None and ctx.needs_input_grad[1]:
             d_means2D = red(g["means2D"]).reshape(shp2)
-        grads = (
-            red(g["means3D"]).reshape(shp3),
-            d_means2D,
-            red(g["shs"]),
-            red(g["colors_precomp"]),
-            red(g["opacities"]).reshape(shpo),
-            red(g["scales"]),
-            red(g["rotations"]),
-            red(g["cov3D_precomp"]),
-            None, None, None, None, None, None, None, None,
-        )
-        ctx.batch = None
-        return grads
+        return (red(g["means3D"]).reshape(shp3), d_means2D, red(g["shs"]), red(g["colors_precomp"]),
+                red(g["opacities"]).reshape(shpo), red(g["scales"]), red(g["rotations"]), red(g["cov3D_precomp"]), None)
+
+
+def _none_if_empty(t):
+    return None if (t is None or t.numel() == 0) else t
 
 
 def rasterize_views(settings: Sequence[GaussianRasterizationSettings], means3D, means2D, opacities, shs=None,
@@ -520,21 +589,53 @@ def rasterize_views(settings: Sequence[GaussianRasterizationSettings], means3D, 
         raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
     H, W, smod, deg = _check_common(settings)
     views = pack_views(settings, means3D.device)
-    empty = torch.empty(0, device=means3D.device)
-    nz = lambda t: empty if t is None else t
     debug = any(bool(s.debug) for s in settings)
     pref = any(bool(s.prefiltered) for s in settings)
     cam_key = tuple(id(s_) for s_ in settings)           # Settings tuples are built once per camera per frame (train.py:98)
-    return _RasterizeViews.apply(means3D, means2D, nz(shs), nz(colors_precomp), opacities, nz(scales),
-                                 nz(rotations), nz(cov3D_precomp), views, H, W, smod, deg, debug, pref, cam_key)
+    spec = _CallSpec(views, H, W, smod, deg, debug, pref, cam_key)
+    return _RasterizeViews.apply(means3D, means2D, _none_if_empty(shs), _none_if_empty(colors_precomp), opacities,
+                                 _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3D_precomp), spec)
+
+
+_SPECS = {}         # id(settings) -> (settings, view-record version, _CallSpec): the one-view drop-in's per-camera constants
+
+
+def _spec_of(s: GaussianRasterizationSettings, device) -> _CallSpec:
+    hit = _SPECS.get(id(s))
+    ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, device)
+    if hit is not None and hit[0] is s and hit[1] == ver:
+        return hit[2]
+    views = pack_views((s,), device)
+    debug = bool(s.debug)
+    spec = _CallSpec(views, int(s.image_height), int(s.image_width), float(s.scale_modifier), int(s.sh_degree), debug,
+                     bool(s.prefiltered), (id(s),), None, True)
+    if len(_SPECS) >= _VIEW_CACHE_MAX:                   # Topo4D builds new camera tuples every frame: forget the oldest half
+        for old in list(_SPECS)[: _VIEW_CACHE_MAX // 2]:
+            del _SPECS[old]
+    _SPECS[id(s)] = (s, ver, spec)
+    return spec
 
 
 class GaussianRasterizer(nn.Module):
-    """Drop-in for `diff_gaussian_rasterization.GaussianRasterizer` (constructed per call at train.py:307)."""
+    """Drop-in for `diff_gaussian_rasterization.GaussianRasterizer` (constructed per call at train.py:307).
+
+    Topo4D builds one of these per ITERATION, so construction is on the hot path: the nn.Module machinery (a dozen dicts) is
+    set up lazily, the first time anything asks for it (`.to()`, `.parameters()`, hooks ...), and calling the object goes
+    straight to `forward` (nn.Module.__call__ only adds the hook dispatch, and a freshly built module has no hooks)."""
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
-        super().__init__()
-        self.raster_settings = raster_settings
+        object.__setattr__(self, "raster_settings", raster_settings)
+
+    def __getattr__(self, name):
+        if "_modules" not in self.__dict__:                 # first use of the nn.Module state
+            nn.Module.__init__(self)
+            return getattr(self, name)
+        return nn.Module.__getattr__(self, name)
+
+    def __call__(self, *args, **kwargs):
+        if "_forward_hooks" in self.__dict__ and (self._forward_hooks or self._forward_pre_hooks):
+            return nn.Module.__call__(self, *args, **kwargs)
+        return self.forward(*args, **kwargs)
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         """Boolean mask of Gaussians that pass the near-plane test of this camera."""
@@ -558,6 +659,12 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        color, radii, depth, alpha = rasterize_views([self.raster_settings], means3D, means2D, opacities, shs,
-                                                     colors_precomp, scales, rotations, cov3D_precomp)
-        return color[0], radii[0], depth[0], alpha[0]
+        if not means3D.is_cuda:
+            raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+        spec = _spec_of(self.raster_settings, means3D.device)
+        if not _SYNC_MODE_EXPLICIT and spec.sync_mode is None:
+            spec.sync_mode = "auto"          # the optimisation-loop default of the one-view drop-in (see set_sync_mode)
+        elif _SYNC_MODE_EXPLICIT and spec.sync_mode is not None:
+            spec.sync_mode = None
+        # (color[3,H,W], radii[P], depth[1,H,W], alpha[1,H,W]) - the four tensors train.py:307 unpacks
+        return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, spec)
