@@ -22,5 +22,26 @@ for name, fn, reps in (("fused_hip", fused, 50), ("torch_per_view", ref, 5)):
     for _ in range(reps): fn()
     torch.cuda.synchronize()
     out[name + "_ms_per_24_views"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+# the library call alone (no autograd glue): HIP events around back-to-back calls -> kernel time of the loss + gradient
+import ctypes as C
+from topo4d_amd import _lib
+lib = _lib.load()
+def raw(V_, H_, W_, reps=40):
+    a = torch.rand(V_, 3, H_, W_, device="cuda"); b = torch.rand(V_, 3, H_, W_, device="cuda")
+    l = torch.empty(V_, device="cuda"); d = torch.empty_like(a)
+    nb = lib.t4d_photometric_scratch_bytes(V_, H_, W_); sc = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: lib.t4d_photometric_loss(V_, H_, W_, p(a), p(b), None, None, None, p(l), p(d), None, None, p(sc), nb, st)
+    for _ in range(5): call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): call()
+    e1.record(); torch.cuda.synchronize()
+    return round(1e3 * e0.elapsed_time(e1) / reps, 1)
+out["kernels_us_24x512x512"] = raw(24, 512, 512)
+out["kernels_us_1x512x375"] = raw(1, 512, 375)
+out["kernels_us_24x2048x2048"] = raw(24, 2048, 2048, 5)
+out["alg_bytes_24x512x512"] = 24 * 3 * 512 * 512 * 12          # read im + gt, write dL/dim
 out["speedup"] = round(out["torch_per_view_ms_per_24_views"] / out["fused_hip_ms_per_24_views"], 1)
 print(json.dumps(out))

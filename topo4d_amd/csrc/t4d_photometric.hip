@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/topo4d_raster.h"
 
@@ -39,8 +40,9 @@ namespace {
 // window slots are compile-time register names (no shifting).  One barrier per row; the only redundancy is the warm-up of a
 // segment (20 rows) and the 10 halo columns of a strip.
 constexpr int kR = 5;              // window radius (11 taps)
-constexpr int kFT = 128;           // threads per workgroup = columns of the first stage
-constexpr int kFTW = kFT - 2 * kR; // output columns of a strip (at most)
+// threads per workgroup = columns of the first stage = output columns of a strip + 10: the launch picks the instantiation
+// (64, 128, 192 or 256 threads) that covers the image width with the fewest thread-columns (512 wide: 3 strips of 171 columns
+// on 192 threads; 375 wide: 7 strips of 54 on 64 threads)
 constexpr int kBlock = 256;        // (k_photo_final and the masked-L1 kernels)
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
@@ -68,12 +70,20 @@ __device__ __forceinline__ float block_sum(float v, float *s_red)
 }
 
 template <int N> struct IC { static constexpr int value = N; };
+typedef float v2f __attribute__((ext_vector_type(2)));      // packed-math pair: one v_pk_fma_f32 does two of the filter's multiply-adds
 
-__global__ __launch_bounds__(kFT) void k_photo_fused(const PhP P)
+#ifndef T4D_PH_WAVES
+#define T4D_PH_WAVES 3             // 166 registers: three waves per SIMD (four = 128 registers spills in the row loop: 258 -> 427 us)
+#endif
+template <int kFT>
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_WAVES, T4D_PH_WAVES))) void k_photo_fused(const PhP P)
 {
     constexpr int kInW = kFT + 2 * kR;                   // input columns a row needs: 138
     __shared__ float2 s_in[2][kInW];                     // (x', gt) of the current row, zero padded
-    __shared__ float s_d[2][3][kFT + 2];                 // adjoint row (D1, D2, D3) at the first stage's columns
+    // adjoint row (D1, D2 | D3) at the first stage's columns (+ slack: the last ten threads of the second stage read beyond them
+    // and emit nothing)
+    __shared__ float2 s_d01[2][kFT + 2 * kR + 2];
+    __shared__ float s_d2[2][kFT + 2 * kR + 2];
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int vc = blockIdx.z, v = vc / 3;
@@ -98,16 +108,19 @@ __global__ __launch_bounds__(kFT) void k_photo_fused(const PhP P)
     const int lx0 = xs - 2 * kR + tid, lx1 = lx0 + kFT;
     const bool l0 = lx0 >= 0 && lx0 < P.W, l1 = tid < 2 * kR && lx1 < P.W;
 
-    float h[11][5], hd[11][3];                           // the two register windows (slots are compile-time indices)
+    // the two register windows (slots are compile-time indices); pairs of maps share a 64-bit register pair so that the
+    // vertical sums run as packed multiply-adds: (x, y), (x^2, y^2) | xy  and  (D1, D2) | D3
+    v2f h01[11], h23[11], hd01[11];
+    float h4[11], hd2[11];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
-#pragma unroll
-        for (int m = 0; m < 5; m++) h[k][m] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 3; m++) hd[k][m] = 0.f;
+        h01[k] = h23[k] = hd01[k] = (v2f){ 0.f, 0.f };
+        h4[k] = hd2[k] = 0.f;
     }
-#pragma unroll
-    for (int m = 0; m < 3; m++) s_d[0][m][tid] = s_d[1][m][tid] = 0.f;      // the first iteration's second stage reads a row nobody wrote
+    for (int b = 0; b < 2; b++) {                        // the first iteration's second stage reads a row nobody wrote
+        s_d01[b][tid] = make_float2(0.f, 0.f); s_d2[b][tid] = 0.f;
+        if (tid < 2 * kR + 2) { s_d01[b][kFT + tid] = make_float2(0.f, 0.f); s_d2[b][kFT + tid] = 0.f; }
+    }
     float sum_l1 = 0.f, sum_s = 0.f, sum_gm = 0.f, sum_gc = 0.f;
     const int i_first = y0 - 2 * kR, i_last = y1 + 2 * kR;      // input rows i_first .. i_last (the last one only drains)
 
@@ -138,62 +151,76 @@ __global__ __launch_bounds__(kFT) void k_photo_fused(const PhP P)
         const bool emit = col2 && o_row >= y0 && o_row < y1;
         float o_im = 0.f, o_gt = 0.f;
         if (emit) { o_im = im[(size_t)o_row * P.W + gx2]; o_gt = gt[(size_t)o_row * P.W + gx2]; }
+#ifndef T4D_PH_NOBARRIER          // (timing experiment: what the one barrier per row costs; results are wrong without it)
         __syncthreads();
+#endif
         // ---- first stage, horizontal: 11 taps of (x, y, x^2, y^2, xy) at this thread's column
         {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+            v2f a01 = { 0.f, 0.f }, a23 = { 0.f, 0.f };
+            float a4 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                const float2 ab = s_in[buf][tid + k];
-                const float wa = w[k] * ab.x, wb = w[k] * ab.y;
-                a0 += wa; a1 += wb; a2 = fmaf(wa, ab.x, a2); a3 = fmaf(wb, ab.y, a3); a4 = fmaf(wa, ab.y, a4);
+                const v2f ab = *reinterpret_cast<const v2f *>(&s_in[buf][tid + k]);
+                const v2f wab = w[k] * ab;                       // four instructions per tap for the five sums
+                a01 += wab;
+                a23 = __builtin_elementwise_fma(wab, ab, a23);
+                a4 = fmaf(wab.x, ab.y, a4);
             }
-            h[J][0] = a0; h[J][1] = a1; h[J][2] = a2; h[J][3] = a3; h[J][4] = a4;
+            h01[J] = a01; h23[J] = a23; h4[J] = a4;
         }
         // ---- first stage, vertical: rows i-10 .. i are in slots J+1 .. J+11 (mod 11) -> the filtered maps at row s = i - 5
         {
-            float mu1 = 0.f, mu2 = 0.f, ea = 0.f, ec = 0.f, eb = 0.f;
+            v2f m12 = { 0.f, 0.f }, eac = { 0.f, 0.f };
+            float eb = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                constexpr int dummy = 0; (void)dummy;
                 const int sl = (J + 1 + k) % 11;
-                mu1 = fmaf(w[k], h[sl][0], mu1); mu2 = fmaf(w[k], h[sl][1], mu2); ea = fmaf(w[k], h[sl][2], ea);
-                ec = fmaf(w[k], h[sl][3], ec); eb = fmaf(w[k], h[sl][4], eb);
+                const v2f wk = { w[k], w[k] };
+                m12 = __builtin_elementwise_fma(wk, h01[sl], m12);
+                eac = __builtin_elementwise_fma(wk, h23[sl], eac);
+                eb = fmaf(w[k], h4[sl], eb);
             }
+            const float mu1 = m12.x, mu2 = m12.y, ea = eac.x, ec = eac.y;
             const int srow = i - kR;
             float d1 = 0.f, d2 = 0.f, d3 = 0.f;
-            if (col1 && srow >= 0 && srow < P.H) {
+            if (col1 && srow >= 0 && srow < P.H) {               // the adjoint map exists inside the image only
                 const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
                 const float s11 = ea - mu1s, s22 = ec - mu2s, s12 = eb - mu12;
                 const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
-                const float inv = 1.f / (B1 * B2);
+                const float inv = 1.f / (B1 * B2);               // the one division of the pixel: 1/B1 = B2 * inv, 1/B2 = B1 * inv
                 const float S = A1 * A2 * inv;
                 // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
-                d1 = g * ((2.f * mu2 * (A2 - A1)) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2));
-                d2 = g * (-S / B2);
-                d3 = g * (2.f * A1 * inv);
+                const float gi = g * inv;
+                d1 = 2.f * gi * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
+                d2 = -gi * S * B1;
+                d3 = 2.f * gi * A1;
                 if (own1 && srow >= y0 && srow < y1) sum_s += S;
             }
-            s_d[buf][0][tid] = d1; s_d[buf][1][tid] = d2; s_d[buf][2][tid] = d3;
+            s_d01[buf][tid] = make_float2(d1, d2); s_d2[buf][tid] = d3;
         }
         // ---- second stage on the adjoint row written ONE iteration ago (made visible by this iteration's barrier)
         {
             const int pb = buf ^ 1;
-            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            v2f q01 = { 0.f, 0.f };
+            float q2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                q0 = fmaf(w[k], s_d[pb][0][tid + k < kFT ? tid + k : kFT - 1], q0);
-                q1 = fmaf(w[k], s_d[pb][1][tid + k < kFT ? tid + k : kFT - 1], q1);
-                q2 = fmaf(w[k], s_d[pb][2][tid + k < kFT ? tid + k : kFT - 1], q2);
+                const v2f wk = { w[k], w[k] };
+                q01 = __builtin_elementwise_fma(wk, *reinterpret_cast<const v2f *>(&s_d01[pb][tid + k]), q01);
+                q2 = fmaf(w[k], s_d2[pb][tid + k], q2);
             }
             constexpr int J2 = (J + 10) % 11;            // the adjoint row of the previous iteration sits one slot back
-            hd[J2][0] = q0; hd[J2][1] = q1; hd[J2][2] = q2;
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            hd01[J2] = q01; hd2[J2] = q2;
+            v2f r01 = { 0.f, 0.f };
+            float r2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
                 const int sl = (J2 + 1 + k) % 11;
-                r0 = fmaf(w[k], hd[sl][0], r0); r1 = fmaf(w[k], hd[sl][1], r1); r2 = fmaf(w[k], hd[sl][2], r2);
+                const v2f wk = { w[k], w[k] };
+                r01 = __builtin_elementwise_fma(wk, hd01[sl], r01);
+                r2 = fmaf(w[k], hd2[sl], r2);
             }
+            const float r0 = r01.x, r1 = r01.y;
             if (emit) {
                 const float x = em * o_im + cc, y = o_gt;
                 const float d = x - y;
@@ -345,14 +372,25 @@ T4D_EXPORT int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const f
     return T4D_OK;
 }
 
-// strips and row segments of the fused kernel for an H x W image: strips as even as possible below 118 columns; segments of 64
-// rows for small workloads (more workgroups), 128 rows from a million pixels per batch on (20 warm-up rows each)
-static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty, int *tw, int *th)
+// strips and row segments of the fused kernel for an H x W image: strips as even as possible; segments of 128 rows from 16 M
+// values per batch on, 64 from 2 M, 16 below (one view of Topo4D's 512 x 375 images: more, shorter workgroups - every segment
+// pays 21 warm-up rows, but a lone view is latency-bound)
+static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty, int *tw, int *th, int *threads)
 {
-    *tx = (W + kFTW - 1) / kFTW;
+    int best = 0;
+    long long best_cost = 0;
+    for (int ft = 64; ft <= 256; ft += 64) {
+        const int strips = (W + (ft - 2 * kR) - 1) / (ft - 2 * kR);
+        const long long cost = (long long)strips * ft;
+        if (best == 0 || cost < best_cost) { best = ft; best_cost = cost; }
+    }
+    if (const char *e = getenv("T4D_PH_THREADS")) { const int ft = atoi(e); if (ft == 64 || ft == 128 || ft == 192 || ft == 256) best = ft; }
+    *threads = best;
+    *tx = (W + (best - 2 * kR) - 1) / (best - 2 * kR);
     *tw = (W + *tx - 1) / *tx;
     const long long work = (long long)n_views * 3 * H * W;
-    *th = work >= (1ll << 25) ? 128 : 64;
+    *th = work >= (1ll << 24) ? 128 : (work >= (1ll << 21) ? 64 : 16);
+    if (const char *e = getenv("T4D_PH_ROWS")) *th = atoi(e) > 0 ? atoi(e) : *th;      // experiments
     if (*th > H) *th = H;
     *ty = (H + *th - 1) / *th;
 }
@@ -360,8 +398,8 @@ static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty
 T4D_EXPORT size_t t4d_photometric_scratch_bytes(int32_t n_views, int32_t H, int32_t W)
 {
     if (n_views < 1 || H < 1 || W < 1) return 0;
-    int tx, ty, tw, th;
-    photo_tiling(n_views, H, W, &tx, &ty, &tw, &th);
+    int tx, ty, tw, th, ft;
+    photo_tiling(n_views, H, W, &tx, &ty, &tw, &th, &ft);
     const size_t tiles = (size_t)tx * ty * n_views * 3;
     return 2 * align_up(tiles * 8);
 }
@@ -380,7 +418,8 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     PhP P;
     memset(&P, 0, sizeof(P));
     P.V = n_views; P.H = H; P.W = W;
-    photo_tiling(n_views, H, W, &P.tx, &P.ty, &P.tw, &P.th);
+    int ft = 0;
+    photo_tiling(n_views, H, W, &P.tx, &P.ty, &P.tw, &P.th, &ft);
     if (P.ty > 65535) return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: image too tall%s", "");
     P.im = im; P.gt = gt; P.cam_m = cam_m; P.cam_c = cam_c; P.weight = view_weight;
     P.loss = loss; P.dL_dim = dL_dim; P.dL_dm = dL_dcam_m; P.dL_dc = dL_dcam_c;
@@ -393,7 +432,11 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     for (int i = 0; i < 11; i++) { g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
     for (int i = 0; i < 11; i++) P.win[i] = g[i] / sum;
     hipStream_t stream = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(k_photo_fused, dim3(P.tx, P.ty, n_views * 3), dim3(kFT), 0, stream, P);
+    const dim3 grid(P.tx, P.ty, n_views * 3);
+    if (ft == 64) hipLaunchKernelGGL(k_photo_fused<64>, grid, dim3(64), 0, stream, P);
+    else if (ft == 128) hipLaunchKernelGGL(k_photo_fused<128>, grid, dim3(128), 0, stream, P);
+    else if (ft == 192) hipLaunchKernelGGL(k_photo_fused<192>, grid, dim3(192), 0, stream, P);
+    else hipLaunchKernelGGL(k_photo_fused<256>, grid, dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k_photo_final, dim3(n_views), dim3(kBlock), 0, stream, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_photometric_loss launch: %s", hipGetErrorString(e));
