@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 // A.5 per-Gaussian backward: gather pair records, then the chain rule down to the inputs
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void preprocess_bwd(const KP &kp, const bool SH)
+__device__ __forceinline__ void preprocess_bwd(const KP &kp)
 {
     // One launch index, VIEW fastest: the V workgroups that read the same 256 Gaussians (and their SH rows) are dispatched back to
     // back, and since workgroup b runs on XCD b % 8 every XCD's L2 fetches them once for the V/8 views it serves instead of once
@@ -1716,7 +1716,6 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp, const bool SH)
     float gm[3] = { 0.f, 0.f, 0.f }, g2x = 0.f, g2y = 0.f, gop = 0.f;
     float grgb[3] = { 0.f, 0.f, 0.f }, gsc[3] = { 0.f, 0.f, 0.f }, gq[4] = { 0.f, 0.f, 0.f, 0.f };
     float gcov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    const int K = SH ? (kp.deg + 1) * (kp.deg + 1) : 0;
 
     if (radius > 0) {
         // ---- gather the partial gradients of this Gaussian's tiles ----
@@ -1808,64 +1807,8 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp, const bool SH)
         // view depth -> mean
         gm[0] += view[2] * gdep; gm[1] += view[6] * gdep; gm[2] += view[10] * gdep;
 
-        // colour
-        if (SH) {
-            const float d0[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
-            const float len = sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
-            const float d[3] = { d0[0] / len, d0[1] / len, d0[2] / len };
-            float bas[16], bx[16], by[16], bz[16];
-            sh_basis(kp.deg, d, bas);
-            sh_basis_grad(kp.deg, d, bx, by, bz);
-            const uint32_t cl = kp.clamped[vg];
-            const float *sh = kp.shs + (size_t)g * kp.M * 3;
-            float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
-            float gd[3] = { 0.f, 0.f, 0.f };
-            const float gc[3] = { (cl & 1u) ? 0.f : grgb[0], (cl & 2u) ? 0.f : grgb[1], (cl & 4u) ? 0.f : grgb[2] };
-            if ((kp.M & 3) == 0 && kp.M <= 16) {
-                // 16-byte loads of the coefficients and 16-byte stores of their gradients (rows are 12*M bytes)
-                const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
-                float4 *gsh4 = reinterpret_cast<float4 *>(gsh);
-                float shl[48], o[48];
-#pragma unroll
-                for (int i = 0; i < 12; i++)
-                    if (i * 4 < K * 3) {
-                        const float4 t4 = sh4[i];
-                        shl[4 * i] = t4.x; shl[4 * i + 1] = t4.y; shl[4 * i + 2] = t4.z; shl[4 * i + 3] = t4.w;
-                    }
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        float ov = 0.f;
-                        if (k < K) {
-                            const float sv = shl[k * 3 + ch];
-                            ov = bas[k] * gc[ch];
-                            gd[0] += bx[k] * sv * gc[ch]; gd[1] += by[k] * sv * gc[ch]; gd[2] += bz[k] * sv * gc[ch];
-                        }
-                        o[k * 3 + ch] = ov;
-                    }
-#pragma unroll
-                for (int i = 0; i < 12; i++)
-                    if (i * 4 < kp.M * 3) gsh4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
-            } else {
-                for (int k = 0; k < kp.M; k++) {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        float o = 0.f;
-                        if (k < K) {
-                            const float sv = sh[k * 3 + ch];
-                            o = bas[k] * gc[ch];
-                            gd[0] += bx[k] * sv * gc[ch]; gd[1] += by[k] * sv * gc[ch]; gd[2] += bz[k] * sv * gc[ch];
-                        }
-                        gsh[k * 3 + ch] = o;
-                    }
-                }
-            }
-            const float dot = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];
-#pragma unroll
-            for (int j = 0; j < 3; j++) gm[j] += (gd[j] - d[j] * dot) / len;
-        }
-
+        // colour: with precomputed RGB the pair sums ARE dL/dcolour; with SH colours they go to k_sh_bwd through a scratch
+        // array (kp.dL_dcolors points at it), which also adds the view-direction term to dL/dmeans3D
         // cov3D -> scale, rotation
         if (!kp.cov3D_precomp) {
             float R[9];
@@ -1894,14 +1837,6 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp, const bool SH)
             gq[2] = 2.f * x * (D[1] + D[3]) + 2.f * r * (D[2] - D[6]) + 2.f * z * (D[5] + D[7]) - 4.f * y * (D[0] + D[8]);
             gq[3] = 2.f * r * (D[3] - D[1]) + 2.f * x * (D[2] + D[6]) + 2.f * y * (D[5] + D[7]) - 4.f * z * (D[0] + D[4]);
         }
-    } else if (SH) {
-        float *gsh = kp.dL_dshs + ((size_t)v * kp.P + g) * kp.M * 3;
-        if ((kp.M & 3) == 0) {
-            float4 *gsh4 = reinterpret_cast<float4 *>(gsh);
-            for (int i = 0; i < kp.M * 3 / 4; i++) gsh4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            for (int k = 0; k < kp.M * 3; k++) gsh[k] = 0.f;
-        }
     }
 
     kp.dL_dmeans3D[vg * 3] = gm[0]; kp.dL_dmeans3D[vg * 3 + 1] = gm[1]; kp.dL_dmeans3D[vg * 3 + 2] = gm[2];
@@ -1917,17 +1852,107 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp, const bool SH)
     }
 }
 
-// Two entry points: without the SH rows (Topo4D's precomputed RGB) the body needs 76 registers instead of 142 and runs at six
-// waves per SIMD instead of three.  (With SH as a compile-time `true` the allocator lands at 181 registers = two waves: the SH
-// entry point keeps the run-time test.)
 #ifndef T4D_PBWD_WAVES
 #define T4D_PBWD_WAVES 6
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T4D_PBWD_WAVES, T4D_PBWD_WAVES))) void k_preprocess_bwd(const KP kp)
 {
-    preprocess_bwd(kp, false);
+    preprocess_bwd(kp);
 }
-__global__ __launch_bounds__(kBlock) void k_preprocess_bwd_sh(const KP kp) { preprocess_bwd(kp, kp.shs != nullptr); }
+
+// SH colours (BASELINE config 4): dL/dshs and the view-direction term of dL/dmeans3D, AFTER k_preprocess_bwd.  Rounds 1-2 did
+// this inside the per-Gaussian kernel: 48 coefficients AND 48 gradients per thread in registers took it to 137 registers
+// (three waves per SIMD), both with 192-byte lane strides - 484 us at config 4, a quarter of the vector ALUs busy.  Here:
+//   1. one thread per (view, Gaussian): direction, basis, masked dL/dcolour; the coefficients stream through (they are only
+//      needed for the gradient of the view direction, sum_k grad(basis_k) * (sh_k . dL/dcolour), which goes to dL/dmeans3D);
+//      basis and dL/dcolour go to LDS;
+//   2. the workgroup writes dL/dshs[k][c] = basis_k * dL/dcolour_c of its 256 Gaussians as ONE contiguous 48 KiB stream,
+//      16 bytes per lane - 553 MB per step at config 4, the bulk of this kernel's traffic.
+// Launch index view-fastest, like k_preprocess_bwd: the V workgroups that read the same coefficient rows run back to back.
+__global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
+{
+    __shared__ float s_bas[kBlock][17];                  // basis (odd pitch: one row per lane without bank conflicts)
+    __shared__ float s_gc[kBlock][4];                    // masked dL/dcolour (zero for an invisible Gaussian)
+    const int tid = threadIdx.x;
+    const uint32_t pblock = blockIdx.x / (uint32_t)kp.V;
+    const int v = (int)(blockIdx.x - pblock * (uint32_t)kp.V);
+    const int g0 = (int)pblock * kBlock;
+    const int n = min(kBlock, kp.P - g0);                // Gaussians of this workgroup
+    const int M3 = kp.M * 3;
+    // ---- 1. per Gaussian
+    if (tid < n) {
+        const int g = g0 + tid;
+        const size_t vg = (size_t)v * kp.P + g;
+        // a truncated forward (arena overflow without T4D_FLAG_CHECKED) returns zero gradients everywhere
+        const bool vis = kp.status->overflow == 0u && kp.radii[vg] > 0;
+        float gc[3] = { 0.f, 0.f, 0.f };
+        float bas[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) bas[i] = 0.f;
+        if (vis) {
+            const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+            const float d0[3] = { kp.means3D[3 * (size_t)g] - vr[32], kp.means3D[3 * (size_t)g + 1] - vr[33], kp.means3D[3 * (size_t)g + 2] - vr[34] };
+            const float len = sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+            const float d[3] = { d0[0] / len, d0[1] / len, d0[2] / len };
+            float bx[16], by[16], bz[16];
+            sh_basis(kp.deg, d, bas);
+            sh_basis_grad(kp.deg, d, bx, by, bz);
+            const uint32_t cl = kp.clamped[vg];                                   // channels the forward clamped at zero carry no gradient
+            const float *grgb = kp.dL_dcolors + vg * 3;                           // the pair sums, left here by k_preprocess_bwd
+            gc[0] = (cl & 1u) ? 0.f : grgb[0]; gc[1] = (cl & 2u) ? 0.f : grgb[1]; gc[2] = (cl & 4u) ? 0.f : grgb[2];
+            const int K = (kp.deg + 1) * (kp.deg + 1);
+            float gd[3] = { 0.f, 0.f, 0.f };
+            const float *sh = kp.shs + (size_t)g * M3;
+            if ((kp.M & 3) == 0 && K == 16) {            // degree 3, 16-byte aligned rows: twelve 16-byte loads, consumed as they come
+                const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
+                float c[48];
+#pragma unroll
+                for (int i = 0; i < 12; i++) { const float4 t4 = sh4[i]; c[4 * i] = t4.x; c[4 * i + 1] = t4.y; c[4 * i + 2] = t4.z; c[4 * i + 3] = t4.w; }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const float t = c[3 * k] * gc[0] + c[3 * k + 1] * gc[1] + c[3 * k + 2] * gc[2];
+                    gd[0] += bx[k] * t; gd[1] += by[k] * t; gd[2] += bz[k] * t;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < K) {
+                        const float t = sh[k * 3] * gc[0] + sh[k * 3 + 1] * gc[1] + sh[k * 3 + 2] * gc[2];
+                        gd[0] += bx[k] * t; gd[1] += by[k] * t; gd[2] += bz[k] * t;
+                    } else {
+                        bas[k] = 0.f;
+                    }
+                }
+            }
+            const float dot = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];         // the direction was normalised: project its gradient
+            float *gm = kp.dL_dmeans3D + vg * 3;
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++) gm[jj] += (gd[jj] - d[jj] * dot) / len;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) s_bas[tid][i] = bas[i];
+        s_gc[tid][0] = gc[0]; s_gc[tid][1] = gc[1]; s_gc[tid][2] = gc[2];
+    }
+    __syncthreads();
+    // ---- 2. dL/dshs, as one contiguous stream
+    float *out = kp.dL_dshs + ((size_t)v * kp.P + g0) * M3;
+    if (kp.M == 16) {
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        for (int i = tid; i < n * 12; i += kBlock) {
+            const int slot = i / 12, e0 = (i % 12) * 4;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = s_bas[slot][(e0 + e) / 3] * s_gc[slot][(e0 + e) % 3];
+            out4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        // (coefficients beyond degree 3 - M > 16 - have no basis function: zero gradient)
+        for (int i = tid; i < n * M3; i += kBlock) {
+            const int slot = i / M3, e = i % M3, k = e / 3;
+            out[i] = k < 16 ? s_bas[slot][k] * s_gc[slot][e % 3] : 0.f;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // per-view scalar <a, b> (e.g. the loss term sum(colour * dL/dcolour) each rank contributes to the loss gather):
@@ -2132,12 +2157,15 @@ T4D_EXPORT size_t t4d_state_bytes(const T4DProblem *prob)
 }
 
 size_t grad_pair_bytes(const T4DProblem &p) { return align_up((size_t)p.n_views * (size_t)p.pair_capacity * kGP * sizeof(float)); }
+size_t tile_dot_bytes(const T4DProblem &p, size_t n_tiles) { return align_up((size_t)p.n_views * n_tiles * 4 * sizeof(float)); }
 
 T4D_EXPORT size_t t4d_backward_scratch_bytes(const T4DProblem *prob)
 {
     if (check_problem(prob) != T4D_OK) return 0;
     const size_t n_tiles = (size_t)((prob->W + T4D_TILE_X - 1) / T4D_TILE_X) * ((prob->H + T4D_TILE_Y - 1) / T4D_TILE_Y);
-    return grad_pair_bytes(*prob) + align_up((size_t)prob->n_views * n_tiles * 4 * sizeof(float));   // pair records | per-wave tile dots
+    // pair records | per-wave tile dots | (SH colours) dL/dcolour per (view, Gaussian), handed from k_preprocess_bwd to k_sh_bwd
+    return grad_pair_bytes(*prob) + tile_dot_bytes(*prob, n_tiles) +
+           (prob->sh_coeffs > 0 ? align_up((size_t)prob->n_views * (size_t)prob->P * 3 * sizeof(float)) : 0);
 }
 
 T4D_EXPORT int t4d_debug_state_layout(const T4DProblem *prob, int has_sh, uint64_t *offsets, int n)
@@ -2288,8 +2316,11 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
     const dim3 pgrid(((p.P + kBlock - 1) / kBlock + (kp.tile_dot ? 1 : 0)) * p.n_views);
-    if (kp.shs) hipLaunchKernelGGL(k_preprocess_bwd_sh, pgrid, dim3(kBlock), 0, stream, kp);
-    else hipLaunchKernelGGL(k_preprocess_bwd, pgrid, dim3(kBlock), 0, stream, kp);
+    if (kp.shs)          // SH colours: the per-Gaussian kernel leaves dL/dcolour in the scratch, k_sh_bwd takes it from there
+        kp.dL_dcolors = (float *)((char *)io->scratch + grad_pair_bytes(p) + tile_dot_bytes(p, (size_t)kp.T));
+    hipLaunchKernelGGL(k_preprocess_bwd, pgrid, dim3(kBlock), 0, stream, kp);
+    if (kp.shs)
+        hipLaunchKernelGGL(k_sh_bwd, dim3((unsigned)(((p.P + kBlock - 1) / kBlock) * p.n_views)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;
