@@ -235,6 +235,16 @@ int t4d_texture_bake(const float *vertices, const int32_t *triangles, const floa
                      int32_t h, int32_t w, int32_t c, int32_t row_begin, int32_t row_end, float *image, float *depth_buffer,
                      void *scratch, size_t scratch_bytes, int64_t pair_capacity, int64_t *pairs_needed, void *hip_stream);
 
+/* The reference's `render_colors(vertices, triangles, colors, h, w, c, BG)` as ONE call (face3d/mesh/render.py:52-86: image =
+ * BG or zeros, depth_buffer = -999999, then _render_colors_core): `image` and `depth_buffer` are pure OUTPUTS here - every
+ * texel of rows [row_begin,row_end) is written, winner or background (`background` [h,w,c] or NULL = zeros) - so the caller
+ * fills nothing and the kernel reads no depth buffer (8192^2: 1.07 GB of fills and 0.27 GB of reads less than
+ * t4d_texture_bake).  Same results bit for bit, same scratch (t4d_texture_bake_scratch_bytes) and overflow protocol. */
+int t4d_texture_render_colors(const float *vertices, const int32_t *triangles, const float *colors, const float *background,
+                              int32_t nver, int32_t ntri, int32_t h, int32_t w, int32_t c, int32_t row_begin, int32_t row_end,
+                              float *image, float *depth_buffer, void *scratch, size_t scratch_bytes, int64_t pair_capacity,
+                              int64_t *pairs_needed, void *hip_stream);
+
 /* Optional per-kernel timing with HIP events recorded on the stream the kernels are launched on.  Between
  * t4d_profile_begin() and t4d_profile_end() every kernel launch of this library is bracketed by two events;
  * t4d_profile_end() synchronises them and returns, per kernel, the summed elapsed time and the launch count.

@@ -143,3 +143,30 @@ def test_sharded_bake_through_rccl_with_one_rank(tmp_path):
     a, b = np.load(out), np.load(out + ".single.npy")
     assert a.shape == (250, 250, 3) and a.any()
     np.testing.assert_array_equal(a, b)
+
+
+def test_in_out_entry_two_passes_equal_one_pass():
+    """`t4d_texture_bake` keeps `_render_colors_core`'s in/out buffers (mesh_core.h:63-69): baking the first half of the triangles
+    and then the second half onto the SAME image and depth buffer is the reference's serial walk cut in two - identical to one pass."""
+    import ctypes as C
+    from topo4d_amd import _lib, texture
+    lib = _lib.load()
+    h, w = 300, 260
+    verts, tris, colors = uv_mesh(70, h, w, 9, True)
+    ref, dref = TX.render_colors_cpu(verts, tris, colors, h, w, return_depth=True)
+    v, t, c = (torch.as_tensor(np.ascontiguousarray(x)).cuda() for x in (verts.astype(np.float32), tris.astype(np.int32),
+                                                                           colors.astype(np.float32)))
+    image = torch.zeros(h, w, 3, device="cuda")
+    depth = torch.full((h, w), -999999.0, device="cuda")
+    half = tris.shape[0] // 2
+    p = lambda x: C.c_void_p(x.data_ptr())
+    for part in (t[:half].contiguous(), t[half:].contiguous()):
+        cap = 8 * int(part.shape[0]) + 65536
+        nb = lib.t4d_texture_bake_scratch_bytes(h, w, cap)
+        sc = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        need = C.c_int64(0)
+        rc = lib.t4d_texture_bake(p(v), p(part), p(c), int(v.shape[0]), int(part.shape[0]), h, w, 3, 0, h, p(image), p(depth), p(sc), nb,
+                                  cap, C.byref(need), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, _lib.last_error()
+    np.testing.assert_array_equal(image.cpu().numpy(), ref)
+    np.testing.assert_array_equal(depth.cpu().numpy(), dref)

@@ -27,7 +27,7 @@ EXPORTS = (
     "t4d_abi_version", "t4d_last_error", "t4d_state_bytes", "t4d_backward_scratch_bytes",
     "t4d_rasterize_forward", "t4d_rasterize_backward", "t4d_fetch_status", "t4d_mark_visible",
     "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end", "t4d_view_dot", "t4d_view_dot_scratch_bytes",
-    "t4d_texture_bake", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
+    "t4d_texture_bake", "t4d_texture_render_colors", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
     "t4d_masked_l1_loss", "t4d_masked_l1_scratch_bytes",
     "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
 )
@@ -120,6 +120,9 @@ def load():
     lib.t4d_texture_bake.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64,
                                      C.POINTER(C.c_int64), C.c_void_p]
+    lib.t4d_texture_render_colors.restype = C.c_int
+    lib.t4d_texture_render_colors.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                              C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
     lib.t4d_photometric_scratch_bytes.restype = C.c_size_t
     lib.t4d_photometric_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.t4d_photometric_loss.restype = C.c_int

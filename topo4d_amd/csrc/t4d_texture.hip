@@ -8,8 +8,9 @@
 // The reference walks the triangles serially and z-tests with a strict `>`, so a texel ends up with the triangle
 // of maximum interpolated depth and, among equals, the LOWEST index (for Topo4D every depth is 0: first triangle
 // wins).  That final state is order-independent, which is what makes a parallel formulation exact:
-//   k_tex_count / k_tex_scan / k_tex_fill   bin triangles by the 32x32-texel tiles their clipped pixel bbox touches
-//                                           (one atomic per pair; the scan runs in 1024-bin chunks on as many workgroups)
+//   k_tex_bin<count> / k_tex_scan / k_tex_bin<fill>   bin triangles by the 32x32-texel tiles their clipped pixel bbox touches
+//                                           (LDS histogram per workgroup, one global atomic per touched tile; the scan runs in
+//                                           1024-bin chunks on as many workgroups)
 //   k_tex_render                            one workgroup per tile: like the reference, a triangle visits only the texels of
 //                                           its bounding box (a wave per triangle, lanes over the box), and the texels keep the
 //                                           lexicographic max of (depth, -index) through an LDS 64-bit integer maximum
@@ -54,6 +55,7 @@ struct TexP {
     uint32_t *bin_count, *bin_cursor, *bin_off, *chunk_sum, *list;
     unsigned long long *total;
     float *image, *depth;
+    const float *bg;              // FRESH launches: background image [h,w,c] or nullptr = zeros
 };
 
 // pixel bbox exactly as mesh_core.cpp:190-199, additionally clipped to the row band
@@ -71,16 +73,75 @@ __device__ __forceinline__ bool tri_bbox(const TexP &P, const int i, int &x_min,
     return !(y_max < P.row_begin || y_min >= P.row_end);
 }
 
-__global__ __launch_bounds__(kBlock) void k_tex_count(const TexP P)
+// Counting and filling go through a per-workgroup LDS histogram over the bounding box (in tiles) of everything the workgroup's
+// 256 triangles touch: triangles that are neighbours in the index buffer are neighbours in UV space, so a workgroup hits a
+// handful of tiles and sends ONE global atomic per touched tile instead of one per (triangle, tile) pair (device-scope atomics
+// are fabric transactions on this chip: 2.8 M of them cost 97 + 168 us of the 8192^2 bake).  A workgroup whose box exceeds the
+// histogram (an index buffer in random order) falls back to per-pair atomics.
+constexpr int kTexHist = 1024;
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_tex_bin(const TexP P)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P.ntri) return;
+    __shared__ int s_bb[4];
+    __shared__ uint32_t s_hist[kTexHist], s_hbase[kTexHist];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = blockIdx.x * kBlock + tid;
     int x_min, x_max, y_min, y_max;
-    if (!tri_bbox(P, i, x_min, x_max, y_min, y_max)) return;
-    const int bx0 = x_min / kTile, bx1 = x_max / kTile;
-    const int by0 = max(y_min, P.row_begin) / kTile - P.by0, by1 = min(y_max, P.row_end - 1) / kTile - P.by0;
-    for (int by = by0; by <= by1; by++)
-        for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&P.bin_count[by * P.bx + bx], 1u);
+    const bool on = i < P.ntri && tri_bbox(P, i, x_min, x_max, y_min, y_max);
+    int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+    if (on) {
+        bx0 = x_min / kTile; bx1 = x_max / kTile;
+        by0 = max(y_min, P.row_begin) / kTile - P.by0; by1 = min(y_max, P.row_end - 1) / kTile - P.by0;
+    }
+    if (tid == 0) { s_bb[0] = 0x7fffffff; s_bb[1] = 0x7fffffff; s_bb[2] = -1; s_bb[3] = -1; }
+    __syncthreads();
+    {
+        int a0 = on ? bx0 : 0x7fffffff, a1 = on ? by0 : 0x7fffffff, a2 = on ? bx1 : -1, a3 = on ? by1 : -1;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            a0 = min(a0, __shfl_xor(a0, d, 64)); a1 = min(a1, __shfl_xor(a1, d, 64));
+            a2 = max(a2, __shfl_xor(a2, d, 64)); a3 = max(a3, __shfl_xor(a3, d, 64));
+        }
+        if (lane == 0) { atomicMin(&s_bb[0], a0); atomicMin(&s_bb[1], a1); atomicMax(&s_bb[2], a2); atomicMax(&s_bb[3], a3); }
+    }
+    __syncthreads();
+    const int ox = s_bb[0], oy = s_bb[1], bw = s_bb[2] - s_bb[0] + 1, bh = s_bb[3] - s_bb[1] + 1;
+    if (s_bb[2] < 0) return;                                       // nothing of this workgroup is in the band
+    const int area = bw * bh;
+    if (area <= kTexHist) {
+        for (int e = tid; e < area; e += kBlock) s_hist[e] = 0;
+        __syncthreads();
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&s_hist[(by - oy) * bw + (bx - ox)], 1u);
+        __syncthreads();
+        for (int e = tid; e < area; e += kBlock) {
+            const uint32_t c = s_hist[e];
+            if (c == 0) continue;
+            const int b = (oy + e / bw) * P.bx + (ox + e % bw);
+            if (FILL) { s_hbase[e] = P.bin_off[b] + atomicAdd(&P.bin_cursor[b], c); s_hist[e] = 0; }
+            else atomicAdd(&P.bin_count[b], c);
+        }
+        if (!FILL) return;
+        __syncthreads();
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int e = (by - oy) * bw + (bx - ox);
+                const uint32_t pos = s_hbase[e] + atomicAdd(&s_hist[e], 1u);
+                if (pos < P.cap) P.list[pos] = (uint32_t)i;
+            }
+    } else {
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int b = by * P.bx + bx;
+                if (FILL) {
+                    const uint32_t pos = P.bin_off[b] + atomicAdd(&P.bin_cursor[b], 1u);
+                    if (pos < P.cap) P.list[pos] = (uint32_t)i;
+                } else {
+                    atomicAdd(&P.bin_count[b], 1u);
+                }
+            }
+    }
 }
 
 __global__ __launch_bounds__(kScanChunk) void k_tex_chunk_sums(const TexP P)
@@ -135,22 +196,6 @@ __global__ __launch_bounds__(kScanChunk) void k_tex_scan(const TexP P)
     const unsigned long long off = carry + woff + incl - c;
     if (b < nb) P.bin_off[b] = off > 0xffffffffull ? 0xffffffffu : (uint32_t)off;
     if (tid == 0 && chunk == P.n_chunks - 1) *P.total = carry + tot;
-}
-
-__global__ __launch_bounds__(kBlock) void k_tex_fill(const TexP P)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P.ntri) return;
-    int x_min, x_max, y_min, y_max;
-    if (!tri_bbox(P, i, x_min, x_max, y_min, y_max)) return;
-    const int bx0 = x_min / kTile, bx1 = x_max / kTile;
-    const int by0 = max(y_min, P.row_begin) / kTile - P.by0, by1 = min(y_max, P.row_end - 1) / kTile - P.by0;
-    for (int by = by0; by <= by1; by++)
-        for (int bx = bx0; bx <= bx1; bx++) {
-            const int b = by * P.bx + bx;
-            const uint32_t pos = P.bin_off[b] + atomicAdd(&P.bin_cursor[b], 1u);
-            if (pos < P.cap) P.list[pos] = (uint32_t)i;
-        }
 }
 
 // One workgroup per 32x32-texel tile.  The first version let every texel test every triangle of its tile (3.4 G tests for
@@ -227,60 +272,145 @@ __device__ __forceinline__ void setup_triangle(const TexP &P, const int i, Tri &
     t.idx = i; t.i0 = i0; t.i1 = i1;
 }
 
+// FRESH: the call starts from render.py:72's state - image = background (zeros), depth buffer = -999999 everywhere - which is
+// what `render_colors` always does: the kernel then neither reads the depth buffer nor needs the caller to fill 2 x h x w x 4
+// bytes first; it writes EVERY texel of the band (winner or background).
+// Tiles whose list fits one staging round (<= kStage triangles: every tile of a UV mesh baked at the usual 8 texels per edge)
+// take the fast path: the list is rank-sorted by triangle index, so that a staged record's SLOT orders like its index and the
+// key can carry the slot ("lowest index wins on equal depth" = "lowest slot wins"); the records stay in LDS together with
+// their vertex colours, and the write-out reads the winner's record from LDS instead of gathering triangle -> vertices ->
+// colours per texel (1.0 of the 1.48 ms of the 8192^2 bake in round 2).
+constexpr float kFreshDepth = -999999.0f;
+constexpr int kMaxC = 4;                                 // colour channels the fast path stages (Topo4D: 3)
+
+template <bool FRESH>
 __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
 {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) Tri s_tri[kStage];
+    __shared__ float s_col[kStage][3][kMaxC];
+    __shared__ uint32_t s_idx[2][kStage];
     __shared__ unsigned long long s_key[kTile * kTile];
-    __shared__ float s_depth[kTile * kTile];
+    __shared__ float s_depth[FRESH ? 1 : kTile * kTile];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const int bxi = b % P.bx, byi = b / P.bx + P.by0;
     const uint32_t n = P.bin_count[b];
-    if (n == 0) return;
-    const uint32_t off = P.bin_off[b];
     const int tx0 = bxi * kTile, ty0 = byi * kTile;
     // rows of the tile that belong to this call's band and to the image
     const int ry_lo = max(ty0, P.row_begin), ry_hi = min(min(ty0 + kTile, P.h), P.row_end) - 1, rx_hi = min(tx0 + kTile, P.w) - 1;
+    constexpr int kPer = kTile * kTile / kBlock;
+    if (n == 0) {
+        if (FRESH) {                                               // nobody draws here: background and the initial depth
+#pragma unroll
+            for (int j = 0; j < kPer; j++) {
+                const int e = tid + j * kBlock;
+                const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+                if (x > rx_hi || y < ry_lo || y > ry_hi) continue;
+                const size_t o = (size_t)y * P.w + x;
+                for (int k = 0; k < P.c; k++) P.image[o * P.c + k] = P.bg ? P.bg[o * P.c + k] : 0.f;
+                P.depth[o] = kFreshDepth;
+            }
+        }
+        return;
+    }
+    const uint32_t off = P.bin_off[b];
     for (int e = tid; e < kTile * kTile; e += kBlock) {           // the caller's depth buffer for this tile: read once, tested from LDS
-        const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
         s_key[e] = 0ull;
-        s_depth[e] = (x <= rx_hi && y >= ry_lo && y <= ry_hi) ? P.depth[(size_t)y * P.w + x] : 0.f;
+        if (!FRESH) {
+            const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+            s_depth[e] = (x <= rx_hi && y >= ry_lo && y <= ry_hi) ? P.depth[(size_t)y * P.w + x] : 0.f;
+        }
+    }
+    const bool fast = n <= (uint32_t)kStage && P.c <= kMaxC && off + n <= P.cap;
+    if (fast) {
+        // ---- rank-sort the list by triangle index (indices are unique inside a bin)
+        if (tid < (int)n) s_idx[0][tid] = P.list[off + tid];
+        __syncthreads();
+        if (tid < (int)n) {
+            const uint32_t mine = s_idx[0][tid];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < n; q++) rank += s_idx[0][q] < mine ? 1u : 0u;
+            s_idx[1][rank] = mine;
+        }
+        __syncthreads();
+        // ---- records + vertex colours of every triangle of the tile
+        if (tid < (int)n) {
+            const int i = (int)s_idx[1][tid];
+            Tri t;
+            setup_triangle(P, i, t);
+            s_tri[tid] = t;
+            const int i2 = P.triangles[3 * (size_t)i + 2];
+            for (int k = 0; k < P.c; k++) {
+                s_col[tid][0][k] = P.colors[(size_t)P.c * t.i0 + k];
+                s_col[tid][1][k] = P.colors[(size_t)P.c * t.i1 + k];
+                s_col[tid][2][k] = P.colors[(size_t)P.c * i2 + k];
+            }
+        }
+        __syncthreads();
     }
     for (uint32_t base = 0; base < n; base += kStage) {
         const int cnt = (int)min((uint32_t)kStage, n - base);
-        __syncthreads();
-        if (tid < cnt) {
-            Tri t;
-            if (off + base + tid < P.cap) setup_triangle(P, (int)P.list[off + base + tid], t);
-            else { memset(&t, 0, sizeof(t)); t.x_min = 1; t.x_max = 0; t.y_min = 1; t.y_max = 0; t.idx = 0x7fffffff; }     // matches no texel
-            s_tri[tid] = t;
+        if (!fast) {
+            __syncthreads();
+            if (tid < cnt) {
+                Tri t;
+                if (off + base + tid < P.cap) setup_triangle(P, (int)P.list[off + base + tid], t);
+                else { memset(&t, 0, sizeof(t)); t.x_min = 1; t.x_max = 0; t.y_min = 1; t.y_max = 0; t.idx = 0x7fffffff; }     // matches no texel
+                s_tri[tid] = t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int k = wave; k < cnt; k += kBlock / 64) {           // wave-uniform: one record per wave at a time
             const Tri t = s_tri[k];
             const int x_lo = max(t.x_min, tx0), x_hi = min(t.x_max, rx_hi), y_lo = max(t.y_min, ry_lo), y_hi = min(t.y_max, ry_hi);
             const int rw = x_hi - x_lo + 1, rh = y_hi - y_lo + 1;
             if (rw <= 0 || rh <= 0) continue;
             const int npx = rw * rh;
+            const uint32_t tag = fast ? (uint32_t)k : (uint32_t)t.idx;     // sorted slot or triangle index: lower wins on equal depth
             for (int p = lane; p < npx; p += 64) {
                 const int dy = p / rw, x = x_lo + (p - dy * rw), y = y_lo + dy;
                 const float px = (float)x, py = (float)y;
                 const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;      // mesh_core.cpp:211
                 const TriEval ev = eval_texel(t, px, py, border);
                 // `pd > depth_buffer` against the caller's buffer first (also drops NaN); later rivals meet in the LDS maximum
-                if (ev.pass && ev.pd > s_depth[(y - ty0) * kTile + (x - tx0)])
-                    atomicMax(&s_key[(y - ty0) * kTile + (x - tx0)],
-                              ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~(uint32_t)t.idx);
+                const float have = FRESH ? kFreshDepth : s_depth[(y - ty0) * kTile + (x - tx0)];
+                if (ev.pass && ev.pd > have)
+                    atomicMax(&s_key[(y - ty0) * kTile + (x - tx0)], ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~tag);
             }
         }
     }
     __syncthreads();
     // The image is [h, w, c]: a texel's c floats sit 4c bytes from its neighbour's; consecutive lanes therefore take
     // consecutive texels of a tile row (the stores of a wave cover whole cache lines between them).
+    if (fast) {
+        // the winner's record and colours are still in LDS: same record, same operations as in the loop above
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int e = tid + j * kBlock;
+            const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+            if (x > rx_hi || y < ry_lo || y > ry_hi) continue;
+            const unsigned long long key = s_key[e];
+            const size_t o = (size_t)y * P.w + x;
+            if (key == 0ull) {                                     // nobody drew this texel
+                if (FRESH) {
+                    for (int k = 0; k < P.c; k++) P.image[o * P.c + k] = P.bg ? P.bg[o * P.c + k] : 0.f;
+                    P.depth[o] = kFreshDepth;
+                }
+                continue;
+            }
+            const int slot = (int)~(uint32_t)key;
+            const float px = (float)x, py = (float)y;
+            const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;
+            const TriEval ev = eval_texel(s_tri[slot], px, py, border);
+            for (int k = 0; k < P.c; k++)
+                P.image[o * P.c + k] = ev.w0 * s_col[slot][0][k] + ev.w1 * s_col[slot][1][k] + ev.w2 * s_col[slot][2][k];
+            P.depth[o] = ev.pd;
+        }
+        return;
+    }
     // Four texels per thread, their dependent gathers (triangle -> vertices -> colours) issued level by level for all four:
     // the chain's latency is paid once per workgroup, not once per texel.
-    constexpr int kPer = kTile * kTile / kBlock;
     int wi[kPer], wv[kPer][3];
     bool hit[kPer];
 #pragma unroll
@@ -304,9 +434,16 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
         }
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
-        if (!hit[j]) continue;
         const int e = tid + j * kBlock;
         const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+        if (!hit[j]) {
+            if (FRESH && x <= rx_hi && y >= ry_lo && y <= ry_hi) {
+                const size_t o = (size_t)y * P.w + x;
+                for (int k = 0; k < P.c; k++) P.image[o * P.c + k] = P.bg ? P.bg[o * P.c + k] : 0.f;
+                P.depth[o] = kFreshDepth;
+            }
+            continue;
+        }
         Tri t;
         setup_from_vertices(vx[j][0], vy[j][0], vx[j][1], vy[j][1], vx[j][2], vy[j][2], vz[j][0], vz[j][1], vz[j][2], t);
         const float px = (float)x, py = (float)y;
@@ -348,10 +485,10 @@ T4D_EXPORT size_t t4d_texture_bake_scratch_bytes(int32_t h, int32_t w, int64_t p
     return tex_layout(h, w, pair_capacity).bytes;
 }
 
-T4D_EXPORT int t4d_texture_bake(const float *vertices, const int32_t *triangles, const float *colors, int32_t nver, int32_t ntri,
-                                int32_t h, int32_t w, int32_t c, int32_t row_begin, int32_t row_end, float *image,
-                                float *depth_buffer, void *scratch, size_t scratch_bytes, int64_t pair_capacity,
-                                int64_t *pairs_needed, void *hip_stream)
+namespace {
+int texture_bake_impl(const bool fresh, const float *bg, const float *vertices, const int32_t *triangles, const float *colors, int32_t nver,
+                      int32_t ntri, int32_t h, int32_t w, int32_t c, int32_t row_begin, int32_t row_end, float *image, float *depth_buffer,
+                      void *scratch, size_t scratch_bytes, int64_t pair_capacity, int64_t *pairs_needed, void *hip_stream)
 {
     if (!vertices || !triangles || !colors || !image || !depth_buffer || !scratch || nver < 1 || ntri < 0 || h < 1 || w < 1 || c < 1)
         return t4d_internal_fail(T4D_ERR_ARG, "t4d_texture_bake: bad arguments%s", "");
@@ -378,28 +515,51 @@ T4D_EXPORT int t4d_texture_bake(const float *vertices, const int32_t *triangles,
     P.chunk_sum = (uint32_t *)(sc + L.chunk_sum);
     P.n_chunks = (P.bx * P.by + kScanChunk - 1) / kScanChunk;
     P.list = (uint32_t *)(sc + L.list);
-    P.image = image; P.depth = depth_buffer;
+    P.image = image; P.depth = depth_buffer; P.bg = bg;
     if (pairs_needed) *pairs_needed = 0;
-    if (ntri == 0) return T4D_OK;
 #define TEX_HIP(call)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
     } while (0)
     TEX_HIP(hipMemsetAsync(sc, 0, L.zero_end, stream));
-    const int gt = (ntri + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_tex_count, dim3(gt), dim3(kBlock), 0, stream, P);
-    if (P.n_chunks > 1) hipLaunchKernelGGL(k_tex_chunk_sums, dim3(P.n_chunks), dim3(kScanChunk), 0, stream, P);
-    hipLaunchKernelGGL(k_tex_scan, dim3(P.n_chunks), dim3(kScanChunk), 0, stream, P);
     unsigned long long total = 0;
-    TEX_HIP(hipMemcpyAsync(&total, P.total, 8, hipMemcpyDeviceToHost, stream));
-    TEX_HIP(hipStreamSynchronize(stream));          // once per bake (a per-frame export step, not the training loop)
-    if (pairs_needed) *pairs_needed = (int64_t)total;
-    if (total > (unsigned long long)pair_capacity)
-        return t4d_internal_fail(T4D_ERR_PAIR_OVERFLOW, "t4d_texture_bake: pair_capacity too small%s", "");
-    hipLaunchKernelGGL(k_tex_fill, dim3(gt), dim3(kBlock), 0, stream, P);
-    hipLaunchKernelGGL(k_tex_render, dim3(P.bx * P.by), dim3(kBlock), 0, stream, P);
+    if (ntri > 0) {
+        const int gt = (ntri + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_tex_bin<false>, dim3(gt), dim3(kBlock), 0, stream, P);
+        if (P.n_chunks > 1) hipLaunchKernelGGL(k_tex_chunk_sums, dim3(P.n_chunks), dim3(kScanChunk), 0, stream, P);
+        hipLaunchKernelGGL(k_tex_scan, dim3(P.n_chunks), dim3(kScanChunk), 0, stream, P);
+        TEX_HIP(hipMemcpyAsync(&total, P.total, 8, hipMemcpyDeviceToHost, stream));
+        TEX_HIP(hipStreamSynchronize(stream));          // once per bake (a per-frame export step, not the training loop)
+        if (pairs_needed) *pairs_needed = (int64_t)total;
+        if (total > (unsigned long long)pair_capacity)
+            return t4d_internal_fail(T4D_ERR_PAIR_OVERFLOW, "t4d_texture_bake: pair_capacity too small%s", "");
+        hipLaunchKernelGGL(k_tex_bin<true>, dim3(gt), dim3(kBlock), 0, stream, P);
+    } else if (!fresh) {
+        return T4D_OK;
+    }
+    if (fresh) hipLaunchKernelGGL(k_tex_render<true>, dim3(P.bx * P.by), dim3(kBlock), 0, stream, P);
+    else hipLaunchKernelGGL(k_tex_render<false>, dim3(P.bx * P.by), dim3(kBlock), 0, stream, P);
     TEX_HIP(hipGetLastError());
 #undef TEX_HIP
     return T4D_OK;
+}
+}  // namespace
+
+T4D_EXPORT int t4d_texture_bake(const float *vertices, const int32_t *triangles, const float *colors, int32_t nver, int32_t ntri,
+                                int32_t h, int32_t w, int32_t c, int32_t row_begin, int32_t row_end, float *image,
+                                float *depth_buffer, void *scratch, size_t scratch_bytes, int64_t pair_capacity,
+                                int64_t *pairs_needed, void *hip_stream)
+{
+    return texture_bake_impl(false, nullptr, vertices, triangles, colors, nver, ntri, h, w, c, row_begin, row_end, image, depth_buffer,
+                             scratch, scratch_bytes, pair_capacity, pairs_needed, hip_stream);
+}
+
+T4D_EXPORT int t4d_texture_render_colors(const float *vertices, const int32_t *triangles, const float *colors, const float *background,
+                                         int32_t nver, int32_t ntri, int32_t h, int32_t w, int32_t c, int32_t row_begin,
+                                         int32_t row_end, float *image, float *depth_buffer, void *scratch, size_t scratch_bytes,
+                                         int64_t pair_capacity, int64_t *pairs_needed, void *hip_stream)
+{
+    return texture_bake_impl(true, background, vertices, triangles, colors, nver, ntri, h, w, c, row_begin, row_end, image, depth_buffer,
+                             scratch, scratch_bytes, pair_capacity, pairs_needed, hip_stream);
 }

@@ -5,7 +5,7 @@ Mirrors, name for name:
   process_uv(uv_coords, uv_h, uv_w)                       helpers.py:945-950
   render_colors(vertices, triangles, colors, h, w, c, BG) face3d/mesh/render.py:52-86   (-> _render_colors_core)
   write_texture(path, uvs, colors, faces, res)            helpers.py:953-960
-over `t4d_texture_bake` (include/topo4d_raster.h).  Results are bit-identical to the reference's CPU code
+over `t4d_texture_render_colors` (include/topo4d_raster.h).  Results are bit-identical to the reference's CPU code
 (tests/test_gpu_texture.py compares with the reference's own source compiled into oracle/_ref).
 There is no CPU path here either.
 """
@@ -53,13 +53,18 @@ def render_colors(vertices, triangles, colors, h: int, w: int, c: int = 3, BG=No
     col = _dev(colors, torch.float32, device)
     if v.dim() != 2 or v.shape[1] != 3 or t.dim() != 2 or t.shape[1] != 3 or col.shape != (v.shape[0], c):
         raise ValueError("vertices [nver,3], triangles [ntri,3], colors [nver,c] expected")
-    if BG is None:
-        image = torch.zeros(h, w, c, dtype=torch.float32, device=device)
-    else:
-        image = _dev(BG, torch.float32, device).clone()
-        assert image.shape == (h, w, c)
-    depth = torch.full((h, w), -999999.0, dtype=torch.float32, device=device)        # render.py:72
     r0, r1 = (0, h) if rows is None else (int(rows[0]), int(rows[1]))
+    bg = None if BG is None else _dev(BG, torch.float32, device)
+    if bg is not None:
+        assert bg.shape == (h, w, c)
+    if (r0, r1) == (0, h):
+        # the whole image: the kernel writes every texel (winner or background) - nothing to fill first
+        image = torch.empty(h, w, c, dtype=torch.float32, device=device)
+        depth = torch.empty(h, w, dtype=torch.float32, device=device)
+    else:
+        # a band: the rows outside it keep the background / the initial depth (render.py:72)
+        image = torch.zeros(h, w, c, dtype=torch.float32, device=device) if bg is None else bg.clone()
+        depth = torch.full((h, w), -999999.0, dtype=torch.float32, device=device)
     key = (device.index, int(t.shape[0]), h, w)
     cap = _CAP.get(key, max(65536, 4 * int(t.shape[0])))
     need = C.c_int64(0)
@@ -67,16 +72,17 @@ def render_colors(vertices, triangles, colors, h: int, w: int, c: int = 3, BG=No
     for _ in range(4):
         nbytes = lib.t4d_texture_bake_scratch_bytes(h, w, cap)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        rc = lib.t4d_texture_bake(C.c_void_p(v.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(col.data_ptr()),
-                                  int(v.shape[0]), int(t.shape[0]), h, w, c, r0, r1, C.c_void_p(image.data_ptr()),
-                                  C.c_void_p(depth.data_ptr()), C.c_void_p(scratch.data_ptr()), nbytes, cap,
-                                  C.byref(need), stream)
+        rc = lib.t4d_texture_render_colors(C.c_void_p(v.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(col.data_ptr()),
+                                           None if bg is None else C.c_void_p(bg.data_ptr()),
+                                           int(v.shape[0]), int(t.shape[0]), h, w, c, r0, r1, C.c_void_p(image.data_ptr()),
+                                           C.c_void_p(depth.data_ptr()), C.c_void_p(scratch.data_ptr()), nbytes, cap,
+                                           C.byref(need), stream)
         if rc == T4D_OK:
             break
         if rc == T4D_ERR_PAIR_OVERFLOW:
             cap = int(need.value * 1.25) + 1024
             continue
-        raise RuntimeError(f"t4d_texture_bake failed (code {rc}): {_lib.last_error()}")
+        raise RuntimeError(f"t4d_texture_render_colors failed (code {rc}): {_lib.last_error()}")
     else:
         raise RuntimeError("texture bake: pair capacity kept overflowing")
     _CAP[key] = cap
