@@ -283,6 +283,76 @@ def load_profile_json(name, config, kernel):
         return None
 
 
+def counters_provenance(config, lanes_key=None):
+    """The rocprofv3 counters in profiles/*.json were taken by separate runs (tools/prof.sh, tools/count_lanes.py): "current" when
+    they were taken on the kernel source this run executes (sha256 of csrc/t4d_raster.hip), otherwise "stale"."""
+    import hashlib
+    try:
+        now = hashlib.sha256(open(os.path.join(ROOT, "topo4d_amd", "csrc", "t4d_raster.hip"), "rb").read()).hexdigest()
+    except OSError:
+        return {"kernel_source_sha256": None}
+    out = {"kernel_source_sha256": now[:16]}
+    for name in ("traffic.json", "valu.json", "lanes.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            then = (d.get(lanes_key or config) or {}).get("_kernel_source_sha256") if name == "lanes.json" else (d.get("_kernel_source_sha256") or {}).get(config)
+            out[name] = "missing" if then is None else ("current" if then == now else "stale")
+        except Exception:
+            out[name] = "missing"
+    return out
+
+
+def drop_in_probe(dev):
+    """The schedule Topo4D runs (train.py:661-673) through the UNMODIFIED drop-in: one camera per iteration, `params2rendervar`
+    (the reference's five torch ops, helpers.py:91-100) -> GaussianRasterizer(raster_settings=cam)(**rendervar) -> backward with
+    a supplied dL/dcolour.  P = 8,280, 512x375, default sync mode ("auto").  Host-bound: iterations/s, and the same loop without
+    the torch ops of params2rendervar around it."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from scaffold import reference_boundary as boundary, scene
+    from topo4d_amd import rasterizer
+    H, W = 512, 375
+    p = scene.make_gaussians(69, 120, opacity="A", seed=0)
+    params = {k: torch.nn.Parameter(v.to(dev)) for k, v in p.items()}
+    cams = scene.camera_rig(H, W, n_views=24, device=dev)
+    g = torch.Generator().manual_seed(0)
+    dcs = [(torch.randn(3, H, W, generator=g) / (3 * H * W)).to(dev) for _ in range(24)]
+    rv_fixed = {k: v.detach().clone().requires_grad_(True) for k, v in boundary.params2rendervar(params).items()}
+
+    def it_full(i):
+        rv = boundary.params2rendervar(params)
+        im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
+        im.backward(dcs[i % 24])
+
+    def it_raster(i):
+        im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv_fixed)
+        im.backward(dcs[i % 24])
+
+    def it_torch_only(i):
+        rv = boundary.params2rendervar(params)
+        (rv["means3D"].sum() + rv["rotations"].sum() + rv["opacities"].sum() + rv["scales"].sum() + rv["colors_precomp"].sum()).backward()
+
+    saved = (rasterizer._SYNC_MODE, rasterizer._SYNC_MODE_EXPLICIT)
+    rasterizer._SYNC_MODE_EXPLICIT = False                 # what an unmodified train.py gets: the drop-in's default mode
+    out = {"workload": "1 camera per iteration, P=8280, 512x375, params2rendervar -> GaussianRasterizer -> backward (train.py:661-673)",
+           "sync_mode": "auto (drop-in default)"}
+    try:
+        for name, fn in (("it_per_s", it_full), ("it_per_s_without_params2rendervar", it_raster), ("params2rendervar_only_it_per_s", it_torch_only)):
+            for i in range(60):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            n = 400
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            out[name] = round(n / (time.perf_counter() - t0), 1)
+    finally:
+        rasterizer._SYNC_MODE, rasterizer._SYNC_MODE_EXPLICIT = saved
+    out["note"] = ("host-bound: an iteration is the reference's own torch ops (params2rendervar forward + autograd backward, "
+                   "params2rendervar_only_it_per_s) plus the drop-in call (it_per_s_without_params2rendervar); GPU time per view is single_view.gpu_us_per_view")
+    return out
+
+
 def single_view_probe(dev):
     """The reference's own call shape (train.py:661-673): ONE camera per call, P = 8,280, 512x375.  GPU time per forward +
     backward = sum of the HIP-event durations of the rasterizer's kernels; wall time per un-synchronised call pair too."""
@@ -454,18 +524,31 @@ def main():
         # vector-ALU counters of the committed rocprofv3 --pmc passes (tools/prof.sh -> profiles/valu.json): what actually limits
         # the render kernels.  busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * kernel cycles).
         valu = load_profile_json("valu.json", args.config, dom)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        # What bounds the dominant kernel, FROM THE COUNTERS: the vector ALUs are "busy" SQ_ACTIVE_INST_VALU x 4 / (SIMDs x kernel
+        # cycles) of the time; above 0.6 the kernel is issue-bound and the HBM fraction is low by construction.  `achieved`/`peak`/
+        # `frac` stay the HBM figures the contract asks for; `issue` and `useful_lane_fraction` sit next to them.
+        busy = valu.get("valu_busy") if valu else None
+        lanes_key = args.config + ("" if args.opacity == "A" else "_" + args.opacity)
+        lanes = load_profile_json("lanes.json", lanes_key, "bwd" if dom == "k_render_bwd" else "fwd")
+        issue = None
+        if valu:
+            issue = {"valu_busy": busy, "achieved_inst_per_cycle_per_simd": round(valu["SQ_INSTS_VALU"] / (1024.0 * valu["kernel_cycles"]), 4),
+                     "peak_inst_per_cycle_per_simd": 0.45, "note": "peak = measured v_fma_f32 rate (tools/micro/valu_issue.hip); DPP adds run at 0.23"}
+        roofline = {"bound": ("valu" if busy is not None and busy > 0.6 else "hbm"), "kernel": dom, "achieved": round(ach, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": int(per_kernel[dom] * V), "avg_us": kernels[dom]["avg_us"],
                     "pairs_per_view": int(R_view), "ms_per_step_profiled": round(1e3 * tp / my_steps, 4),
                     "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels,
-                    "valu": valu,
-                    "measured_limiter": ("vector-ALU issue" if valu and valu.get("valu_busy", 0) > 0.6 else None)}
+                    "valu": valu, "issue": issue,
+                    "useful_lane_fraction": (lanes or {}).get("useful_lane_fraction"), "row_balance": (lanes or {}).get("row_balance"),
+                    "counters": counters_provenance(args.config, lanes_key),
+                    "measured_limiter": ("vector-ALU issue" if busy is not None and busy > 0.6 else None)}
     if dist is not None:
         barrier()
 
     # ---- side measurements on one GPU: scenario B (unsaturated opacities) and the reference's one-view-per-call shape ----
-    scenario_b = single_view = None
+    scenario_b = single_view = drop_in = None
     if world == 1 and not args.no_extras:
         try:
             if args.opacity == "A":
@@ -479,6 +562,7 @@ def main():
                               "workload": "same as config.workload with opacity scenario B: uniform(0.05, 0.95)"}
                 del wb
             single_view = single_view_probe(dev)
+            drop_in = drop_in_probe(dev)
         except Exception as e:          # side measurements must never take the headline number down with them
             scenario_b = scenario_b or {"error": str(e)}
         topo4d_amd.set_sync_mode("lazy")
@@ -508,7 +592,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}",
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
                        "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "frames_in_flight": wl.F},
-            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "sequential": sequential,
+            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "drop_in": drop_in, "sequential": sequential,
             ("weak" if args.scaling == "strong" else "strong"): other,
             "dist_backend": (dist.get_backend() if dist is not None else None),
         }

@@ -8,8 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from topo4d_amd import _lib
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
-opa = sys.argv[2] if len(sys.argv) > 2 else "A"
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+cfg = _args[0] if len(_args) > 0 else "C2"
+opa = _args[1] if len(_args) > 1 else "A"
 dev = torch.device("cuda")
 wl = bench.Workload(cfg, opa, dev, in_flight=1)
 wl.learn_capacity()
@@ -32,4 +33,12 @@ for name, o in (("bwd", 0), ("fwd", 8)):
                  "lanes_per_row_visit": round(lanes / max(1, visits), 2),
                  "steps_per_wave_batch": round(steps / max(1, batches), 1),
                  "row_visits_per_pair": round(visits / max(1, int(st.total_pairs)), 2)}
+import hashlib
+out["_kernel_source_sha256"] = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "topo4d_amd", "csrc",
+                                                              "t4d_raster.hip"), "rb").read()).hexdigest()
 print(json.dumps(out))
+if "--merge" in sys.argv:                      # profiles/lanes.json: what bench.py reads for roofline.useful_lane_fraction
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "lanes.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[f"{cfg}{'' if opa == 'A' else '_' + opa}"] = out
+    json.dump(cur, open(path, "w"), indent=1)

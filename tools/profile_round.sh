@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: everything profiles/ keeps for a round - rocprofv3 kernel stats + PMC passes for config 2 (opacity A and B),
+# config 4, the 1M dense pass and the one-view shape; the lane counts of the counting build; the side benches.
+#   usage: tools/profile_round.sh <round tag, e.g. r03>        (outputs under gpurun_out/<tag>_*)
+R=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+tools/prof.sh ${R}_c2 > /dev/null 2>&1
+tools/prof.sh ${R}_c2b --opacity B > /dev/null 2>&1
+tools/prof.sh ${R}_c4 --config C4 > /dev/null 2>&1
+PROF_CMD="python $ROOT/tools/big_case.py" tools/prof.sh ${R}_dense > /dev/null 2>&1
+PROF_CMD="python $ROOT/tools/prof_single_view.py" tools/prof.sh ${R}_single_view > /dev/null 2>&1
+tools/ab_build.sh count -DT4D_COUNT > /dev/null 2>&1
+for a in "C2 A" "C2 B" "C4 A"; do T4D_LIB=$ROOT/topo4d_amd/csrc/variants/lib_count.so python tools/count_lanes.py $a 2>/dev/null | tail -1; done > gpurun_out/${R}_lanes.jsonl
+tools/side_benches.sh ${R}_side > /dev/null 2>&1
+python bench.py > gpurun_out/${R}_bench_c2.json 2> gpurun_out/${R}_bench_c2.err
+python bench.py --config C4 --steps 20 > gpurun_out/${R}_bench_c4.json 2> gpurun_out/${R}_bench_c4.err
+ls gpurun_out | grep ${R}_

@@ -1561,11 +1561,17 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     eval_splat(make_float4(q01.x, q01.y, q23.x, q23.y), ds[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
                 }
+#if T4D_ABL == 40            // timing experiment: no step is treated as a same-splat conflict (wrong sums)
+                const uint32_t cbits = 0u;
+#else
                 const uint32_t cbits = (uint32_t)(conflict_s[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63));
+#endif
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
-                    T4D_COUNT_ADD(4, __builtin_popcountll(__ballot(contrib)));
+#ifdef T4D_COUNT
+                    { const unsigned long long cb_ = __ballot(contrib); T4D_COUNT_ADD(4, __builtin_popcountll(cb_)); }
+#endif
                     const v2f d = ds[u];
                     const float G = Gs[u], alpha = alphas[u];
                     float *dst = reinterpret_cast<float *>(slab + (LAT ? (ee[u] & slab_and) : ee[u]));
