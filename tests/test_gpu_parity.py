@@ -43,12 +43,17 @@ def flipped_pixels(hip, v, r, n_contrib_mine):
     return np.argwhere(bad)
 
 
+FLIP_GRAD_REL = 5e-2
+
+
 def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_KEYS, rel=GRAD_REL):
-    """check_grads where a handful of threshold decisions (`flips`, from flipped_pixels) differ from the oracle: a Gaussian
-    may exceed the relative tolerance ONLY IF a flipped pixel lies in one of the 16x16 tiles of its 3-sigma rectangle - the
-    pixels it is evaluated on: alpha >= 1/255 reaches 3.33 sigma at opacity 1, beyond the 3-sigma radius - where the flip moves
-    that pixel's transmittance for every splat behind the flipped one and the "colour behind" for every splat in front of it.
-    The absolute bound GRAD_ABS holds for all."""
+    """check_grads where a handful of threshold decisions (`flips`, from flipped_pixels) differ from the oracle.  Every Gaussian
+    is held to the plain tolerance (rel * max|reference| per tensor, and GRAD_ABS absolute) EXCEPT those with a flipped pixel in
+    one of the 16x16 tiles of their 3-sigma rectangle - the pixels they are evaluated on: alpha >= 1/255 reaches 3.33 sigma at
+    opacity 1, beyond the 3-sigma radius - where the flip moves that pixel's transmittance for every splat behind the flipped
+    one and the "colour behind" for every splat in front of it.  Such a Gaussian's gradient differs by that pixel's whole
+    contribution (soak seed 962: 1.4e-4 absolute, 0.25 % of the tensor's largest); it is held to FLIP_GRAD_REL of the tensor's
+    largest entry - a sanity bound, not a precision claim."""
     tile = 16.0
     ftx, fty = (flips[:, 1] // 16, flips[:, 0] // 16) if len(flips) else (np.zeros(0), np.zeros(0))
     for k in keys:
@@ -58,13 +63,13 @@ def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_K
         b = np.asarray(ref_g[k], np.float64).reshape(a.shape)
         scale = max(np.abs(b).max(), 1e-30)
         err = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
-        assert err.max() < GRAD_ABS, f"grad {k}[view {v}]: abs err {err.max():.3e}"
-        for i in np.nonzero(err > rel * scale + 1e-9)[0]:
+        for i in np.nonzero((err > rel * scale + 1e-9) | (err >= GRAD_ABS))[0]:
             r = float(radii[i])
             x0, x1 = max(0, int((xy[i, 0] - r) / tile)), int((xy[i, 0] + r + tile - 1) / tile)      # tile_rect of t4d_raster.hip
             y0, y1 = max(0, int((xy[i, 1] - r) / tile)), int((xy[i, 1] + r + tile - 1) / tile)
             near = (ftx >= x0) & (ftx < x1) & (fty >= y0) & (fty < y1)
             assert near.any(), f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} with no flipped pixel in reach"
+            assert err[i] <= FLIP_GRAD_REL * scale, f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} is more than one pixel's share"
 
 
 def check_n_contrib(mine, ref, max_flips=0):
