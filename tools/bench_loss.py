@@ -43,5 +43,8 @@ out["kernels_us_24x512x512"] = raw(24, 512, 512)
 out["kernels_us_1x512x375"] = raw(1, 512, 375)
 out["kernels_us_24x2048x2048"] = raw(24, 2048, 2048, 5)
 out["alg_bytes_24x512x512"] = 24 * 3 * 512 * 512 * 12          # read im + gt, write dL/dim
+out["alg_GBs_24x512x512"] = round(out["alg_bytes_24x512x512"] / (out["kernels_us_24x512x512"] * 1e-6) / 1e9, 1)
+out["alg_GBs_24x2048x2048"] = round(24 * 3 * 2048 * 2048 * 12 / (out["kernels_us_24x2048x2048"] * 1e-6) / 1e9, 1)
+out["bound"] = "vector ALU (two separable 11-tap filters of 5 + 3 maps and the SSIM algebra: ~290 instructions per pixel row and thread)"
 out["speedup"] = round(out["torch_per_view_ms_per_24_views"] / out["fused_hip_ms_per_24_views"], 1)
 print(json.dumps(out))
