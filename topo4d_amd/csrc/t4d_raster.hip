@@ -153,7 +153,7 @@ struct KP {
     float *rgb;
     uint8_t *clamped;
     unsigned long long *keys, *sort_tmp;       // sort_tmp: ping-pong arena for bins longer than the LDS sort buffer
-    uint16_t *touch;                           // [V,cap] sub-block touch mask of every sorted pair: written by the forward's staging, read by the backward's (lives in the pair_rank arena, which is dead once k_scatter has run)
+    float *cut_r2;                             // [V,cap] squared cut-off radius of every sorted pair (cutoff_radius2): written by the forward's staging, read by the backward's (lives in the pair_rank arena, which is dead once k_scatter has run)
     float *final_T;
     uint32_t *n_contrib;
     // forward outputs
@@ -165,7 +165,9 @@ struct KP {
     float *dL_dmeans3D, *dL_dmeans2D, *dL_dcolors, *dL_dshs, *dL_dopacities, *dL_dscales, *dL_drotations, *dL_dcov3D;
     float *tile_dot;         // [V,T,4] per-wave <outputs, cotangents> of every tile (scratch) or nullptr when the caller did not ask
     float *cotangent_dot;    // [V]
-    uint32_t tile_blocks;    // k_render_bwd: workgroups that walk the tile list; the ones behind them do the empty tiles' dots
+    uint32_t tile_blocks;    // k_render_bwd / k_render_fwd: workgroups that walk the tile list (the backward's others do the empty tiles' dots)
+    uint32_t fill_blocks;    // k_render_fwd: workgroups that write the EMPTY tiles' pixels, one per (view, row of tiles)
+    uint32_t fill_vec;       // ... with 16-byte stores (W % 4 == 0 and 16-byte aligned output planes)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -329,6 +331,24 @@ __device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float b
     }
 }
 
+// Launch index of the per-Gaussian kernels -> (block of 256 Gaussians, view).  The V workgroups of one block read the same
+// parameter rows (at config 4: 48 KiB of SH coefficients).  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so the
+// index is decoded such that ALL V workgroups of a block land on the SAME XCD, back to back: blocks go in groups of eight
+// (one per XCD), a group takes 8 V consecutive indices, view-major.  The rows then leave HBM once, not once per XCD (the
+// view-fastest order of round 2) or once per view (block-fastest).  T4D_GB_ORDER: bit 0 k_preprocess, bit 1
+// k_preprocess_bwd, bit 2 k_sh_bwd take this order (experiments; default all).
+#ifndef T4D_GB_ORDER
+#define T4D_GB_ORDER 6
+#endif
+__device__ __forceinline__ bool block_and_view(const uint32_t b, const uint32_t V, const uint32_t nblocks, uint32_t &gb, uint32_t &v)
+{
+    const uint32_t per = 8u * V, grp = b / per, rem = b - grp * per;
+    v = rem >> 3;
+    gb = grp * 8u + (rem & 7u);
+    return gb < nblocks;
+}
+__host__ __device__ inline unsigned gaussian_grid(const int P, const int V) { return (unsigned)((((P + kBlock - 1) / kBlock + 7) / 8) * 8 * V); }
+
 // ---------------------------------------------------------------------------------------------------------
 // A.1 preprocess (+ tile counting + pair-slot allocation)
 // ---------------------------------------------------------------------------------------------------------
@@ -340,8 +360,16 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     __shared__ int s_bb[4];
     __shared__ uint32_t s_hist[kHist], s_hbase[kHist];
     const int tid = threadIdx.x;
-    const int g = blockIdx.x * kBlock + tid;
-    const int v = blockIdx.y;
+    const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
+    uint32_t gb, vb;
+#if T4D_GB_ORDER & 1
+    if (!block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, gb, vb)) return;          // padding of the last group of eight
+#else
+    vb = blockIdx.x / nblocks; gb = blockIdx.x - vb * nblocks;
+    if (vb >= (uint32_t)kp.V) return;
+#endif
+    const int g = (int)gb * kBlock + tid;
+    const int v = (int)vb;
     const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
     const float *view = vr, *proj = vr + 16;
     const size_t vg = (size_t)v * kp.P + g;
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                     kp.xy[vg] = make_float2(px, py);
                     kp.depth[vg] = pvz;
                     kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, kp.opacities[g]);
-                    if (kp.shs) {
+                    if (kp.shs && T4D_ABL != 8) {
                         float d[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
                         const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
                         d[0] /= len; d[1] /= len; d[2] /= len;
@@ -459,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     // Returning atomics on ONE address are served one after the other (~0.2 us each): 117 workgroups per view on one
     // cursor cost this kernel 20 of its 42 us.  The arena is therefore cut into nseg segments with a cursor each;
     // workgroup b allocates from segment b % nseg (neighbouring workgroups hold mesh neighbours, so the fills stay even).
-    const uint32_t seg = blockIdx.x & (kp.nseg - 1u);
+    const uint32_t seg = gb & (kp.nseg - 1u);
     if (tid == 0) s_base = seg * kp.seg_cap + atomicAdd(&kp.view_cursor[v * kCursorSegs + seg], block_tot);
     {   // bounding box (in tiles) of everything this workgroup touches
         int bx0 = tiles ? x0 : 0x7fffffff, by0 = tiles ? y0 : 0x7fffffff, bx1 = tiles ? x1 : 0, by1 = tiles ? y1 : 0;
@@ -644,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
     const int n_pblocks = (kp.P + kBlock - 1) / kBlock;
     if ((int)blockIdx.x >= n_pblocks) {
         // Tail blocks of this launch: flatten the length-ordered tile list into one 16-byte record per work item,
-        // items[b] = (view << 20 | tile, arena offset, list length, -), so that a per-tile workgroup starts with ONE
+        // items[b] = (view << 20 | tile, arena offset, list length, pair count), so that a per-tile workgroup starts with ONE
         // scalar load instead of a chain of dependent loads (there are ~25k such workgroups per launch).
         const uint32_t b = ((uint32_t)blockIdx.y * (gridDim.x - n_pblocks) + (blockIdx.x - n_pblocks)) * kBlock + threadIdx.x;
         if (b >= (uint32_t)(kp.V * kp.T)) return;
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
         const size_t vt = (size_t)(id >> 20) * kp.T + (id & 0xfffffu);
         const uint32_t off = kp.tile_off[vt];
         const uint32_t n = off >= kp.cap ? 0u : min(kp.tile_count[vt], kp.cap - off);
-        kp.items[b] = make_uint4(id, off, n, 0u);
+        kp.items[b] = make_uint4(id, off, n, kp.tile_count[vt]);       // .w = 0: a truly empty tile (n = 0 also after an arena overflow)
         return;
     }
     const int g = blockIdx.x * kBlock + threadIdx.x;
@@ -959,25 +987,27 @@ __device__ __forceinline__ float cutoff_radius2(const float4 co)
     return 2.0f * (lnarg + 2e-3f) / lmin * 1.001f;
 }
 
-// bit (4*w + r) set <=> the splat centred at p with cut-off r2 can touch 4x4 sub-block r of wave w of tile (tx,ty)
-__device__ __forceinline__ uint32_t subblock_touch_mask(const float2 p, const float r2, const int tx, const int ty)
+// Can the splat centred at p with squared cut-off r2 touch a 4x4 sub-block?  Asked for the FOUR sub-blocks of one wave (its DPP
+// rows) at once, answered as wave masks: bit `lane` of out[r] <=> the splat whose centre and cut-off this LANE holds can touch
+// row r of wave w of tile (tx, ty).  Every wave tests the staged splats against its own rows, 64
+// splats per call, and gets the masks where the list builder wants them - in scalar registers; a staging wave computing all
+// sixteen masks per splat, balloting them and handing them over through LDS cost the forward 190 vector instructions per
+// wave and batch against 100 here (round 3).  r2 < 0 (a slot that holds no splat) touches nothing; the centre of such a
+// slot must be finite.
+__device__ __forceinline__ void wave_touch_masks(const float2 p, const float r2, const int tx, const int ty, const int w,
+                                                 unsigned long long (&out)[4])
 {
-    float dx2[4], dy2[4];
+#pragma clang fp contract(off)
+    float dx2[2], dy2[2];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const float x0 = (float)(tx * T4D_TILE_X + 4 * c), y0 = (float)(ty * T4D_TILE_Y + 4 * c);
+    for (int j = 0; j < 2; j++) {
+        const float x0 = (float)(tx * T4D_TILE_X + ((w & 1) << 3) + 4 * j), y0 = (float)(ty * T4D_TILE_Y + ((w >> 1) << 3) + 4 * j);
         const float ddx = fmaxf(fmaxf(x0 - p.x, p.x - (x0 + 3.f)), 0.f);
         const float ddy = fmaxf(fmaxf(y0 - p.y, p.y - (y0 + 3.f)), 0.f);
-        dx2[c] = ddx * ddx; dy2[c] = ddy * ddy;
+        dx2[j] = ddx * ddx; dy2[j] = ddy * ddy;
     }
-    uint32_t m = 0;
 #pragma unroll
-    for (int sb = 0; sb < 16; sb++) {
-        const int w = sb >> 2, r = sb & 3;
-        const int cx = ((w & 1) << 1) | (r & 1), cy = ((w >> 1) << 1) | (r >> 1);
-        if (!(dx2[cx] + dy2[cy] > r2)) m |= 1u << sb;
-    }
-    return m;
+    for (int r = 0; r < 4; r++) out[r] = __ballot(!(dx2[r & 1] + dy2[r >> 1] > r2));
 }
 
 // SGPR copy of lane `src_lane`'s value
@@ -1044,6 +1074,54 @@ __device__ __forceinline__ void pad_visit_list(unsigned short *list, const int c
     for (int p2 = cnt + lane; p2 < nsteps + GROUP - 1; p2 += 64) list[p2] = null_entry;
 }
 
+// The pixels of EMPTY tiles (config 4: two thirds of 2048^2): background colour, zero depth, zero alpha - 20 bytes per pixel that
+// no splat ever touches.  Written tile by tile (a tile's row is 64 bytes of a plane, a wave's store 32) they went to HBM at
+// 2.5 TB/s and made up a third of k_render_fwd at config 4 (803 us for an all-empty launch).  Here one workgroup takes a whole
+// ROW of tiles of a view and walks it in image order, 16 bytes per lane, skipping the tiles that hold splats: neighbouring
+// empty tiles become one long contiguous store per image row.  These workgroups are spread evenly between the tile
+// workgroups of the same launch (k_render_fwd): bandwidth work next to issue-bound work.
+__device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t j)
+{
+    const int tid = threadIdx.x;
+    const int v = (int)(j / (uint32_t)kp.gy), ty = (int)(j - (uint32_t)v * (uint32_t)kp.gy);
+    const uint32_t *tc = kp.tile_count + (size_t)v * kp.T + (size_t)ty * kp.gx;
+    const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+    const float b0 = vr[35], b1 = vr[36], b2 = vr[37];
+    const int y0 = ty * T4D_TILE_Y, rows = min(T4D_TILE_Y, kp.H - y0);
+    const size_t HW = (size_t)kp.H * kp.W;
+    float *oc = kp.out_color + (size_t)v * 3 * HW + (size_t)y0 * kp.W;
+    float *od = kp.out_depth + (size_t)v * HW + (size_t)y0 * kp.W;
+    float *oa = kp.out_alpha + (size_t)v * HW + (size_t)y0 * kp.W;
+    if (kp.fill_vec) {
+        const int qw = kp.W >> 2;                        // 16-byte groups per image row; four of them per tile
+        int r = tid / qw, q = tid - r * qw;
+        const int dr = kBlock / qw, dq = kBlock - dr * qw;
+        while (r < rows) {
+            if (tc[q >> 2] == 0u) {
+                const size_t o = (size_t)r * kp.W + 4 * q;
+                *reinterpret_cast<float4 *>(oc + o) = make_float4(b0, b0, b0, b0);
+                *reinterpret_cast<float4 *>(oc + HW + o) = make_float4(b1, b1, b1, b1);
+                *reinterpret_cast<float4 *>(oc + 2 * HW + o) = make_float4(b2, b2, b2, b2);
+                *reinterpret_cast<float4 *>(od + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(oa + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            r += dr; q += dq;
+            if (q >= qw) { q -= qw; r++; }
+        }
+    } else {
+        int r = tid / kp.W, x = tid - r * kp.W;
+        const int dr = kBlock / kp.W, dx = kBlock - dr * kp.W;
+        while (r < rows) {
+            if (tc[x / T4D_TILE_X] == 0u) {
+                const size_t o = (size_t)r * kp.W + x;
+                oc[o] = b0; oc[HW + o] = b1; oc[2 * HW + o] = b2; od[o] = 0.f; oa[o] = 0.f;
+            }
+            r += dr; x += dx;
+            if (x >= kp.W) { x -= kp.W; r++; }
+        }
+    }
+}
+
 #ifndef T4D_FWD_WAVES
 #define T4D_FWD_WAVES 6          // 80 VGPRs, no spills; 7 waves (72 VGPRs) spill inside the batch loop and measure 5 % slower
 #endif
@@ -1063,20 +1141,28 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     constexpr int kNull = kFwdBatch;                 // staged slot that can never contribute (opacity 0)
     constexpr int kChunks = kFwdBatch / 64;
     constexpr int kListStride = kFwdBatch + 8;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
-    constexpr int kRec = 48;                         // bytes per staged splat: xy (8, +8 pad) | scaled conic + opacity | rgb + depth
+    constexpr int kRec = 48;                         // bytes per staged splat: xy, cut-off r2 (12, +4 pad) | scaled conic + opacity | rgb + depth
+    static_assert(kFwdBatch == kBlock, "every thread stages one slot per batch (and clears it when the list is shorter)");
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFwdBatch + 1) * kRec];
-    __shared__ unsigned long long s_mask[16][kChunks];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
+    // fill workgroups are spread evenly over the launch: workgroup b is one iff floor(b F / total) steps up at b
+    const uint32_t total_blocks = kp.tile_blocks + kp.fill_blocks;
+    const uint32_t fills_before = (uint32_t)(((unsigned long long)blockIdx.x * kp.fill_blocks) / total_blocks);
+    if ((uint32_t)(((unsigned long long)(blockIdx.x + 1u) * kp.fill_blocks) / total_blocks) != fills_before) {
+        fill_empty_tile_row(kp, fills_before);
+        return;
+    }
     if (tid < kRec / 4) reinterpret_cast<float *>(s_rec + kNull * kRec)[tid] = 0.f;
-    for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += gridDim.x) {   // every tile, empty ones last
+    for (uint32_t item = blockIdx.x - fills_before; item < (uint32_t)(kp.V * kp.T); item += kp.tile_blocks) {
     const uint4 it = kp.items[item];
+    if (it.w == 0u) break;                           // ordered by length: only empty tiles remain, and those are not ours
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-    uint16_t *touch_out = kp.touch + (size_t)v * kp.cap + off;
+    float *r2_out = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
     const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
@@ -1091,40 +1177,44 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 
     for (uint32_t b = 0; b < n; b += kFwdBatch) {
         if (__syncthreads_count(done) == kBlock) break;
-        uint32_t touch = 0;
-        if (tid < kFwdBatch && b + tid < n) {
-            const unsigned long long key = keys[b + tid];
-            const uint32_t g = (uint32_t)key;
-            // g >= P only happens in lazy mode after an arena overflow (slots of dropped pairs hold stale bytes):
-            // such entries are ignored instead of being dereferenced
-            if (g < (uint32_t)kp.P) {
-                const float2 p = xy[g];
-                const float4 c = co[g];
-                unsigned char *rec = s_rec + tid * kRec;
-                *reinterpret_cast<float2 *>(rec) = p;
-                *reinterpret_cast<float4 *>(rec + 16) = scale_conic(c);
-                *reinterpret_cast<float4 *>(rec + 32) = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
-                                                                   __uint_as_float((uint32_t)(key >> 32)));
-                touch = subblock_touch_mask(p, cutoff_radius2(c), tx, ty);
+        {
+            float4 head = make_float4(0.f, 0.f, -1.f, 0.f);      // (x, y, cut-off r2, -): a slot without a splat touches nothing
+            if (b + tid < n) {
+                const unsigned long long key = keys[b + tid];
+                const uint32_t g = (uint32_t)key;
+                // g >= P only happens in lazy mode after an arena overflow (slots of dropped pairs hold stale bytes):
+                // such entries are ignored instead of being dereferenced
+                if (g < (uint32_t)kp.P) {
+                    const float2 p = xy[g];
+                    const float4 c = co[g];
+                    unsigned char *rec = s_rec + tid * kRec;
+                    head = make_float4(p.x, p.y, cutoff_radius2(c), 0.f);
+                    *reinterpret_cast<float4 *>(rec + 16) = scale_conic(c);
+                    *reinterpret_cast<float4 *>(rec + 32) = make_float4(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1], rgb[3 * (size_t)g + 2],
+                                                                       __uint_as_float((uint32_t)(key >> 32)));
+                }
+                r2_out[b + tid] = head.z;                // the backward stages the same splats: it reads the cut-off back
             }
-            touch_out[b + tid] = (uint16_t)touch;        // the backward stages the same splats: it reads the mask back
-        }
-        if (wave < kChunks) {
-#pragma unroll
-            for (int sb = 0; sb < 16; sb++) {
-                const unsigned long long bal = __ballot((touch >> sb) & 1u);
-                if (lane == sb) s_mask[sb][wave] = bal;
-            }
+            *reinterpret_cast<float4 *>(s_rec + tid * kRec) = head;
         }
         __syncthreads();
         if (__all(done)) continue;                   // wave-uniform; still takes part in the barriers above
+        // which of the staged splats can touch which of this wave's four sub-blocks (= DPP rows)
+        unsigned long long m[4][kChunks];
+#pragma unroll
+        for (int c4 = 0; c4 < kChunks; c4++) {
+            unsigned long long mc[4] = { 0ull, 0ull, 0ull, 0ull };
+            if (b + ((uint32_t)c4 << 6) < n) {           // wave-uniform: short lists leave most chunks of a batch empty
+                const float4 head = *reinterpret_cast<const float4 *>(s_rec + ((c4 << 6) + lane) * kRec);
+                wave_touch_masks(make_float2(head.x, head.y), head.z, tx, ty, wave, mc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) m[r][c4] = mc[r];
+        }
         int nsteps = 0, cnts[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {                // one visit list per 4x4 sub-block (= DPP row) of this wave
-            unsigned long long m[kChunks];
-#pragma unroll
-            for (int c4 = 0; c4 < kChunks; c4++) m[c4] = uniform_u64(s_mask[wave * 4 + r][c4]);
-            cnts[r] = build_visit_list<kChunks, false, kRec>(m, s_list[wave][r], lane);
+        for (int r = 0; r < 4; r++) {                // one visit list per sub-block
+            cnts[r] = build_visit_list<kChunks, false, kRec>(m[r], s_list[wave][r], lane);
             nsteps = max(nsteps, cnts[r]);
         }
 #pragma unroll
@@ -1328,6 +1418,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     // entry (ten floats), and list entries are slot * 40: the byte offset of BOTH, so a step spends no vector instruction on
     // addresses (records are read as 8-byte words: a 40-byte stride keeps them 8- but not 16-byte aligned).
     constexpr int kEnt = 40;
+    static_assert(kBwdBatch % 64 == 0, "staged slots come in chunks of one per lane");
     static_assert(kGP == kAcc, "the slab entry and the scratch record hold the same ten sums");
     static_assert(kAcc * 4 == kEnt, "a slab entry and a staged record must have the same stride");
     // One struct, so that the layout is ours: the staged records sit at LDS offset 0 and the replay's paired 8-byte reads reach
@@ -1336,7 +1427,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         unsigned char rec[(kBwdBatch + 1) * kEnt];
         float acc[kSlabs][kBwdBatch + 1][kAcc];                 // + the null splat's (never read) row
         unsigned short list[4][4][kListStride];
-        unsigned long long mask[16][kChunks];
+        float cut_r2[kChunks * 64];                             // cut-off of every staged splat (< 0: none in this slot)
         uint32_t pair[kBwdBatch];
         uint32_t wmax[4];
     };
@@ -1346,7 +1437,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     auto &s_rec = sh.rec;
     auto &s_pair = sh.pair;
     auto &s_acc = sh.acc;
-    auto &s_mask = sh.mask;
+    auto &s_r2 = sh.cut_r2;
     auto &s_wmax = sh.wmax;
     auto &s_list = sh.list;
     constexpr int kNull = kBwdBatch;
@@ -1399,7 +1490,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #endif
     if (n == 0) break;                                             // ordered by length: only empty tiles remain
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-    const uint16_t *touch_in = kp.touch + (size_t)v * kp.cap + off;
+    const float *r2_in = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
     const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
@@ -1453,44 +1544,54 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         const int cnt = (int)min((uint32_t)kBwdBatch, n - lo);
         const bool live = lo < tile_max;      // workgroup-uniform
         // ---- stage ----
-        uint32_t touch = 0;
         if (tid < cnt) s_pair[tid] = 0xffffffffu;
-        if (tid < cnt && (uint32_t)keys[lo + tid] < (uint32_t)kp.P) {     // stale entries after an overflow are skipped
-            const unsigned long long key = keys[lo + tid];
-            const uint32_t g = (uint32_t)key;
-            const float2 p = xy[g];
-            int x0, y0, x1, y1;
-            tile_rect(p.x, p.y, radii[g], kp.gx, kp.gy, x0, y0, x1, y1);
-            const int local = (ty - y0) * (x1 - x0) + (tx - x0);
-            s_pair[tid] = (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) ? pair_off[g] + (uint32_t)local : 0xffffffffu;
-            if (live) {
-                const float4 c = co[g];
-                const float4 q4 = scale_conic(c);
-                float2 *rec = reinterpret_cast<float2 *>(s_rec + tid * kEnt);
-                rec[0] = make_float2(q4.x, q4.y); rec[1] = make_float2(q4.z, q4.w);
-                rec[2] = make_float2(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1]);
-                rec[3] = make_float2(rgb[3 * (size_t)g + 2], __uint_as_float((uint32_t)(key >> 32)));
-                rec[4] = p;
-                touch = touch_in[lo + tid];              // = subblock_touch_mask(p, cutoff_radius2(c), tx, ty), kept by the forward
+        if (tid < kChunks * 64) {
+            float r2 = -1.f;                                 // a slot without a splat touches nothing ...
+            float2 p = make_float2(0.f, 0.f);                // ... and holds a finite centre
+            if (tid < cnt && (uint32_t)keys[lo + tid] < (uint32_t)kp.P) {     // stale entries after an overflow are skipped
+                const unsigned long long key = keys[lo + tid];
+                const uint32_t g = (uint32_t)key;
+                p = xy[g];
+                int x0, y0, x1, y1;
+                tile_rect(p.x, p.y, radii[g], kp.gx, kp.gy, x0, y0, x1, y1);
+                const int local = (ty - y0) * (x1 - x0) + (tx - x0);
+                s_pair[tid] = (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) ? pair_off[g] + (uint32_t)local : 0xffffffffu;
+                if (live) {
+                    const float4 c = co[g];
+                    const float4 q4 = scale_conic(c);
+                    float2 *rec = reinterpret_cast<float2 *>(s_rec + tid * kEnt);
+                    rec[0] = make_float2(q4.x, q4.y); rec[1] = make_float2(q4.z, q4.w);
+                    rec[2] = make_float2(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1]);
+                    rec[3] = make_float2(rgb[3 * (size_t)g + 2], __uint_as_float((uint32_t)(key >> 32)));
+                    r2 = r2_in[lo + tid];                    // = cutoff_radius2(c), kept by the forward
+                }
             }
-        }
-        if (wave < kChunks) {
-#pragma unroll
-            for (int sb = 0; sb < 16; sb++) {
-                const unsigned long long bal = __ballot((touch >> sb) & 1u);
-                if (lane == sb) s_mask[sb][wave] = bal;
+            if (live) {
+                reinterpret_cast<float2 *>(s_rec + tid * kEnt)[4] = p;
+                s_r2[tid] = r2;
             }
         }
         __syncthreads();
         T4D_STAMP(9 + 8 * (nb - 1 - bi));
         if (live) {
+            // which of the staged splats can touch which of this wave's four sub-blocks: the forward's test, on the forward's numbers
+            unsigned long long mt[4][kChunks];
+#pragma unroll
+            for (int c2 = 0; c2 < kChunks; c2++) {
+                const int slot = (c2 << 6) + lane;
+                unsigned long long mc[4] = { 0ull, 0ull, 0ull, 0ull };
+                if ((c2 << 6) < cnt)                         // wave-uniform
+                    wave_touch_masks(reinterpret_cast<const float2 *>(s_rec + slot * kEnt)[4], s_r2[slot], tx, ty, wave, mc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) mt[r][c2] = mc[r];
+            }
             int nsteps = 0, cnts[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 unsigned long long m[kChunks];
 #pragma unroll
                 for (int c2 = 0; c2 < kChunks; c2++) {
-                    m[c2] = uniform_u64(s_mask[wave * 4 + r][c2]);
+                    m[c2] = mt[r][c2];
                     // positions at or beyond the row's last contributor cannot matter: drop them from the mask
                     const uint32_t base = lo + ((uint32_t)c2 << 6);
                     if (row_max[r] <= base) m[c2] = 0;
@@ -1686,11 +1787,18 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
     // back, and since workgroup b runs on XCD b % 8 every XCD's L2 fetches them once for the V/8 views it serves instead of once
     // per view (config 4: 516 -> 484 us; the same order made k_preprocess SLOWER, 210 -> 294 us, and is not used there).  The
     // spare workgroups of the per-view dot sit behind all of them.
-    const uint32_t n_pv = (uint32_t)((kp.P + kBlock - 1) / kBlock) * (uint32_t)kp.V;
+    const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
+    const uint32_t n_pv = gaussian_grid(kp.P, kp.V);
     const bool spare = blockIdx.x >= n_pv;
-    const int pblock = (int)(blockIdx.x / (uint32_t)kp.V);
-    const int v = spare ? (int)(blockIdx.x - n_pv) : (int)(blockIdx.x - (uint32_t)pblock * (uint32_t)kp.V);
-    const int g = pblock * kBlock + threadIdx.x;
+    uint32_t gb = 0, vb = 0;
+#if T4D_GB_ORDER & 2
+    if (!spare && !block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, gb, vb)) return;
+#else
+    gb = blockIdx.x / (uint32_t)kp.V; vb = blockIdx.x - gb * (uint32_t)kp.V;
+    if (!spare && gb >= nblocks) return;
+#endif
+    const int v = spare ? (int)(blockIdx.x - n_pv) : (int)vb;
+    const int g = (int)gb * kBlock + threadIdx.x;
     if (spare) {
         // one spare workgroup per view: the view's <outputs, cotangents> = sum of its tiles' dots, in a fixed order
         __shared__ float s_w[4];
@@ -1880,8 +1988,15 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
     __shared__ float s_bas[kBlock][17];                  // basis (odd pitch: one row per lane without bank conflicts)
     __shared__ float s_gc[kBlock][4];                    // masked dL/dcolour (zero for an invisible Gaussian)
     const int tid = threadIdx.x;
-    const uint32_t pblock = blockIdx.x / (uint32_t)kp.V;
-    const int v = (int)(blockIdx.x - pblock * (uint32_t)kp.V);
+    const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
+    uint32_t pblock, vb;
+#if T4D_GB_ORDER & 4
+    if (!block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, pblock, vb)) return;
+#else
+    pblock = blockIdx.x / (uint32_t)kp.V; vb = blockIdx.x - pblock * (uint32_t)kp.V;
+    if (pblock >= nblocks) return;
+#endif
+    const int v = (int)vb;
     const int g0 = (int)pblock * kBlock;
     const int n = min(kBlock, kp.P - g0);                // Gaussians of this workgroup
     const int M3 = kp.M * 3;
@@ -2131,7 +2246,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.order = reinterpret_cast<uint32_t *>(st + L.order);
     kp.items = reinterpret_cast<uint4 *>(st + L.items);
     kp.pair_rank = reinterpret_cast<uint32_t *>(st + L.pair_rank);
-    kp.touch = reinterpret_cast<uint16_t *>(st + L.pair_rank);
+    kp.cut_r2 = reinterpret_cast<float *>(st + L.pair_rank);
     kp.tile_off = reinterpret_cast<uint32_t *>(st + L.tile_off);
     kp.chunk_sum = reinterpret_cast<uint32_t *>(st + L.chunk_sum);
     kp.n_chunks = (kp.T + kScanChunk - 1) / kScanChunk;
@@ -2221,7 +2336,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     T4D_HIP(hipMemsetAsync(st, 0, L.zero_end, stream));
     const dim3 gP((p.P + kBlock - 1) / kBlock, p.n_views);
     { ProfScope ps_(stream, K_PREPROCESS);
-    hipLaunchKernelGGL(k_preprocess, gP, dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_preprocess, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess");
     { ProfScope ps_(stream, K_SCAN_TILES);
@@ -2256,10 +2371,12 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
-    if (latency_launch(kp.T * p.n_views))
-        hipLaunchKernelGGL(k_render_fwd<true>, dim3(kp.T * p.n_views), dim3(kBlock), 0, stream, kp);
-    else
-        hipLaunchKernelGGL(k_render_fwd<false>, dim3(tile_grid(kp.T * p.n_views, 6, 2)), dim3(kBlock), 0, stream, kp);
+    const bool lat = latency_launch(kp.T * p.n_views);
+    kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 6, 2));
+    kp.fill_blocks = (uint32_t)(kp.gy * p.n_views);
+    kp.fill_vec = (p.W % 4 == 0 && (((uintptr_t)io->out_color | (uintptr_t)io->out_depth | (uintptr_t)io->out_alpha) & 15u) == 0) ? 1u : 0u;
+    if (lat) hipLaunchKernelGGL(k_render_fwd<true>, dim3(kp.tile_blocks + kp.fill_blocks), dim3(kBlock), 0, stream, kp);
+    else hipLaunchKernelGGL(k_render_fwd<false>, dim3(kp.tile_blocks + kp.fill_blocks), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
     return T4D_OK;
@@ -2321,12 +2438,12 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);
-    const dim3 pgrid(((p.P + kBlock - 1) / kBlock + (kp.tile_dot ? 1 : 0)) * p.n_views);
+    const dim3 pgrid(gaussian_grid(p.P, p.n_views) + (kp.tile_dot ? p.n_views : 0));
     if (kp.shs)          // SH colours: the per-Gaussian kernel leaves dL/dcolour in the scratch, k_sh_bwd takes it from there
         kp.dL_dcolors = (float *)((char *)io->scratch + grad_pair_bytes(p) + tile_dot_bytes(p, (size_t)kp.T));
     hipLaunchKernelGGL(k_preprocess_bwd, pgrid, dim3(kBlock), 0, stream, kp);
     if (kp.shs)
-        hipLaunchKernelGGL(k_sh_bwd, dim3((unsigned)(((p.P + kBlock - 1) / kBlock) * p.n_views)), dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL(k_sh_bwd, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;
