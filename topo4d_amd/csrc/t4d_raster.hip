@@ -982,9 +982,11 @@ __device__ __forceinline__ float cutoff_radius2(const float4 co)
     const float mid = 0.5f * (co.x + co.z);
     const float det = co.x * co.z - co.y * co.y;
     const float disc = mid * mid - det;
-    const float lmin = det / (mid + sqrtf(fmaxf(disc, 0.f)));  // smallest eigenvalue of the conic, stable form
+    // (hardware square root and reciprocals, ~1 ulp each: the margins below are four orders of magnitude wider, and the IEEE
+    // sequences were 40 of this function's 60 instructions)
+    const float lmin = det * __builtin_amdgcn_rcpf(mid + __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)));   // smallest eigenvalue of the conic, stable form
     if (!(lmin > 0.f) || !(mid > 0.f)) return __builtin_huge_valf();   // not positive definite / NaN: no culling
-    return 2.0f * (lnarg + 2e-3f) / lmin * 1.001f;
+    return 2.0f * (lnarg + 2e-3f) * __builtin_amdgcn_rcpf(lmin) * 1.001f;
 }
 
 // Can the splat centred at p with squared cut-off r2 touch a 4x4 sub-block?  Asked for the FOUR sub-blocks of one wave (its DPP
@@ -1058,7 +1060,8 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
         if (mw == 0ull) continue;                               // wave-uniform: most chunks of most batches are empty
         const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
         const int tot = __builtin_popcountll(mw);
-        if ((mw >> lane) & 1ull) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)(((c << 6) + lane) * SCALE);
+        // the mask is wave-uniform: it becomes the exec mask of the store as it is (a per-lane bit test cost three instructions)
+        if (__builtin_amdgcn_inverse_ballot_w64(mw)) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)(((c << 6) + lane) * SCALE);
         cnt += tot;
     }
     return cnt;
@@ -1145,6 +1148,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     static_assert(kFwdBatch == kBlock, "every thread stages one slot per batch (and clears it when the list is shorter)");
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFwdBatch + 1) * kRec];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
+    __shared__ uint32_t s_wave_done[4];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
     // fill workgroups are spread evenly over the launch: workgroup b is one iff floor(b F / total) steps up at b
@@ -1171,12 +1175,16 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     tile_pixel(tid, tx, ty, px, py);
     const bool inside = px < kp.W && py < kp.H;
     const v2f pix_f = { (float)px, (float)py };
-    bool done = !inside;
+    unsigned long long done_m = __ballot(!inside);   // pixels that take no more splats, as a wave mask
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
     for (uint32_t b = 0; b < n; b += kFwdBatch) {
-        if (__syncthreads_count(done) == kBlock) break;
+        if (b != 0) {                                // a further batch: needed only while some pixel of the tile is unfinished
+            if (lane == 0) s_wave_done[wave] = done_m == ~0ull ? 1u : 0u;
+            __syncthreads();                         // (also: everyone has left the previous batch's records)
+            if ((s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) != 0u) break;
+        }
         {
             float4 head = make_float4(0.f, 0.f, -1.f, 0.f);      // (x, y, cut-off r2, -): a slot without a splat touches nothing
             if (b + tid < n) {
@@ -1198,7 +1206,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             *reinterpret_cast<float4 *>(s_rec + tid * kRec) = head;
         }
         __syncthreads();
-        if (__all(done)) continue;                   // wave-uniform; still takes part in the barriers above
+        if (done_m == ~0ull) continue;               // wave-uniform; still takes part in the barriers above
         // which of the staged splats can touch which of this wave's four sub-blocks (= DPP rows)
         unsigned long long m[4][kChunks];
 #pragma unroll
@@ -1227,7 +1235,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         nsteps = 0;
 #endif
         uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
-        unsigned long long done_m = __ballot(done);
         for (int k = 0; k < nsteps; k += kU) {
             uint32_t e[kU];
 #pragma unroll
@@ -1272,7 +1279,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             T4D_COUNT_ADD(10, kU);
             if (done_m == ~0ull) break;
         }
-        done = __builtin_amdgcn_inverse_ballot_w64(done_m);
         if (last_e != 0xffffffffu) last_contributor = b + ((last_e * 43691u) >> 21) + 1u;     // entry / 48 for entries < 2^17
     }
     if (inside) {
