@@ -448,3 +448,40 @@ def test_cotangent_dot_from_the_backward(with_depth_alpha, bg, render_build):
     dot2 = torch.empty_like(dot)
     batch.backward(*cot, cotangent_dot=dot2)
     assert torch.equal(dot, dot2)                                   # fixed summation order
+
+
+def test_empty_tiles_written_by_row_fill_workgroups(monkeypatch):
+    """Round 3: the pixels of empty tiles (background colour, zero depth and alpha) are written by workgroups of k_render_fwd
+    that walk a ROW of tiles in image order, 16 bytes per lane when the planes allow it, 4 bytes otherwise.  Both paths must
+    leave exactly the image the oracle renders: a sparse scene on a non-black background (most tiles empty), widths that are
+    and are not multiples of four and of the tile size, and both builds of the render kernels."""
+    for H, W in ((96, 128), (70, 100), (33, 90), (16, 4)):
+        rv, cams = util.make_scene(6, 8, H, W, 3, opacity="B", seed=5, bg=(0.25, 0.5, 0.75))
+        ref = [util.c_oracle_render(c, rv)[0] for c in cams]
+        for tiles in ("0", "1000000000"):                    # throughput build, latency build
+            monkeypatch.setenv("T4D_LATENCY_TILES", tiles)
+            outs = []
+            for scalar in (False, True):
+                if scalar:
+                    monkeypatch.setenv("T4D_FILL_SCALAR", "1")
+                else:
+                    monkeypatch.delenv("T4D_FILL_SCALAR", raising=False)
+                # the outputs come from torch.empty: poison the blocks the caching allocator is about to hand out again, so that a
+                # pixel nobody writes shows up as NaN instead of as the previous (correct) image
+                poison = [torch.full((len(cams), c, H, W), float("nan"), device="cuda") for c in (3, 1, 1)]
+                torch.cuda.synchronize()
+                del poison
+                hip, _, batch = util.hip_render(cams, rv)
+                outs.append(hip)
+                for v, r in enumerate(ref):
+                    check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=2)       # (threshold pixels: see flipped_pixels)
+                # the pixels of empty tiles are EXACTLY background / zero, and every one of them is written
+                empty = util.decode_state(batch)["tile_count"].reshape(len(cams), (H + 15) // 16, (W + 15) // 16) == 0
+                assert empty.any() and not empty.all()       # the scene really has both kinds of tiles
+                pix_empty = np.repeat(np.repeat(empty, 16, axis=1), 16, axis=2)[:, :H, :W]
+                for ch, b in enumerate((0.25, 0.5, 0.75)):
+                    assert (hip["color"][:, ch][pix_empty] == np.float32(b)).all()
+                assert (hip["depth"][:, 0][pix_empty] == 0).all() and (hip["alpha"][:, 0][pix_empty] == 0).all()
+            for k in ("color", "depth", "alpha"):
+                assert np.array_equal(outs[0][k], outs[1][k]), k
+    monkeypatch.delenv("T4D_FILL_SCALAR", raising=False)

@@ -11,7 +11,15 @@ tools/prof.sh ${R}_c4 --config C4 > /dev/null 2>&1
 PROF_CMD="python $ROOT/tools/big_case.py" tools/prof.sh ${R}_dense > /dev/null 2>&1
 PROF_CMD="python $ROOT/tools/prof_single_view.py" tools/prof.sh ${R}_single_view > /dev/null 2>&1
 tools/ab_build.sh count -DT4D_COUNT > /dev/null 2>&1
-for a in "C2 A" "C2 B" "C4 A"; do T4D_LIB=$ROOT/topo4d_amd/csrc/variants/lib_count.so python tools/count_lanes.py $a 2>/dev/null | tail -1; done > gpurun_out/${R}_lanes.jsonl
+for a in "C2 A" "C2 B" "C4 A"; do T4D_LIB=$ROOT/topo4d_amd/csrc/variants/lib_count.so python tools/count_lanes.py $a --merge 2>/dev/null | tail -1; done > gpurun_out/${R}_lanes.jsonl
+# the counters go into profiles/*.json HERE too (the box's copy), so that the bench lines below carry them as "current";
+# profiles/ does not travel back: the same merges are repeated in the repository from gpurun_out/ (see profiles/README.md)
+python tools/merge_counters.py gpurun_out/${R}_c2 C2 > /dev/null
+python tools/merge_counters.py gpurun_out/${R}_c2b C2_B > /dev/null
+python tools/merge_counters.py gpurun_out/${R}_c4 C4 > /dev/null
+python tools/merge_counters.py gpurun_out/${R}_dense DENSE_1M > /dev/null
+python tools/merge_counters.py gpurun_out/${R}_single_view SINGLE_VIEW > /dev/null
+cp profiles/traffic.json profiles/valu.json profiles/lanes.json gpurun_out/ 2>/dev/null
 tools/side_benches.sh ${R}_side > /dev/null 2>&1
 python bench.py > gpurun_out/${R}_bench_c2.json 2> gpurun_out/${R}_bench_c2.err
 python bench.py --config C4 --steps 20 > gpurun_out/${R}_bench_c4.json 2> gpurun_out/${R}_bench_c4.err

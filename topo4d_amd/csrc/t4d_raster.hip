@@ -27,10 +27,12 @@
 //                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS)
 //   k_sort_long       A.2  bins beyond 2048 keys (dense passes): a CU each - 1024 threads, 128 KiB of LDS for up to 16,384 keys,
 //                          longer ones chunk-sorted and merged in global memory
-//   k_render_fwd      A.3  per work item: 256 threads = 4 wave64 = 16 DPP rows, one 4x4 sub-block each; front-to-back blend
+//   k_render_fwd      A.3  per work item: 256 threads = 4 wave64 = 16 DPP rows, one 4x4 sub-block each; front-to-back blend;
+//                          empty tiles are written by row-fill workgroups of the same launch (fill_empty_tile_row)
 //   k_render_bwd      A.4  per work item: back-to-front replay, row-local reduction, one record per pair
 //                          (both render kernels exist in a throughput and a latency build: see k_render_fwd)
-//   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D/SH chain rule
+//   k_preprocess_bwd  A.5  per (view,Gaussian): gather pair records, conic/cov2D/projection/cov3D chain rule
+//   k_sh_bwd16, k_sh_bwd   SH colours: dL/dshs and the view-direction term of dL/dmeans3D (degree 3 / any degree)
 //   k_view_dot_*, k_mark_visible: small utilities of the ABI
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -336,7 +338,8 @@ __device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float b
 // index is decoded such that ALL V workgroups of a block land on the SAME XCD, back to back: blocks go in groups of eight
 // (one per XCD), a group takes 8 V consecutive indices, view-major.  The rows then leave HBM once, not once per XCD (the
 // view-fastest order of round 2) or once per view (block-fastest).  T4D_GB_ORDER: bit 0 k_preprocess, bit 1
-// k_preprocess_bwd, bit 2 k_sh_bwd take this order (experiments; default all).
+// k_preprocess_bwd, bit 2 k_sh_bwd take this order (experiments; default: the two backward kernels - k_preprocess is a
+// third SLOWER with it, 211 -> 288 us at config 4, although its fetch traffic falls).
 #ifndef T4D_GB_ORDER
 #define T4D_GB_ORDER 6
 #endif
@@ -669,12 +672,16 @@ __global__ __launch_bounds__(kScanChunk) void k_scan_tiles(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
 {
-    const int n_pblocks = (kp.P + kBlock - 1) / kBlock;
-    if ((int)blockIdx.x >= n_pblocks) {
+    // One launch index: V * nb8 scatter workgroups (nb8 = blocks of 256 Gaussians, rounded up to eight), view after view in block
+    // order, then the workgroups that flatten the tile list.  (Round 3 tried giving every XCD a contiguous eighth of each view's
+    // blocks, so that the partial cache lines of a tile bin meet in one L2: config 4 went from 101 to 133 us.)
+    const uint32_t nb8 = gaussian_grid(kp.P, 1);
+    const uint32_t n_scatter = nb8 * (uint32_t)kp.V;
+    if (blockIdx.x >= n_scatter) {
         // Tail blocks of this launch: flatten the length-ordered tile list into one 16-byte record per work item,
         // items[b] = (view << 20 | tile, arena offset, list length, pair count), so that a per-tile workgroup starts with ONE
         // scalar load instead of a chain of dependent loads (there are ~25k such workgroups per launch).
-        const uint32_t b = ((uint32_t)blockIdx.y * (gridDim.x - n_pblocks) + (blockIdx.x - n_pblocks)) * kBlock + threadIdx.x;
+        const uint32_t b = (blockIdx.x - n_scatter) * kBlock + threadIdx.x;
         if (b >= (uint32_t)(kp.V * kp.T)) return;
         TileOrder ord;
         load_tile_order(kp, ord);
@@ -685,8 +692,8 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
         kp.items[b] = make_uint4(id, off, n, kp.tile_count[vt]);       // .w = 0: a truly empty tile (n = 0 also after an arena overflow)
         return;
     }
-    const int g = blockIdx.x * kBlock + threadIdx.x;
-    const int v = blockIdx.y;
+    const int v = (int)(blockIdx.x / nb8);
+    const int g = (int)(blockIdx.x - (uint32_t)v * nb8) * kBlock + threadIdx.x;
     if (g >= kp.P) return;
     const size_t vg = (size_t)v * kp.P + g;
     const int r = kp.radii[vg];
@@ -950,9 +957,10 @@ __global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
 // 1.6x less often than an 8x8 block, so a wave needs that many fewer steps, every lane still sees its splats in list
 // order (results are bit-identical to a per-pixel walk), and the backward's per-splat reduction runs over 16 lanes with
 // row-local DPP only, for four splats at once.
-// Per staged splat one lane computes, for each of the 16 sub-blocks, a CONSERVATIVE test "can alpha reach 1/255 on any
-// pixel centre of the sub-block?"; the wave64 ballots become per-sub-block bit masks.  Skipped splats would have been
-// rejected by the per-pixel alpha < 1/255 test anyway, so results are unchanged.
+// For every staged splat and sub-block a CONSERVATIVE test "can alpha reach 1/255 on any pixel centre of the sub-block?" decides
+// whether the splat enters the sub-block's list: each wave tests the staged splats (one per lane, 64 at a time) against its
+// own four sub-blocks and keeps the wave64 ballots as the bit masks its list builder walks (wave_touch_masks).  Skipped
+// splats would have been rejected by the per-pixel alpha < 1/255 test anyway, so results are unchanged.
 // ---------------------------------------------------------------------------------------------------------
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -1789,10 +1797,10 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void preprocess_bwd(const KP &kp)
 {
-    // One launch index, VIEW fastest: the V workgroups that read the same 256 Gaussians (and their SH rows) are dispatched back to
-    // back, and since workgroup b runs on XCD b % 8 every XCD's L2 fetches them once for the V/8 views it serves instead of once
-    // per view (config 4: 516 -> 484 us; the same order made k_preprocess SLOWER, 210 -> 294 us, and is not used there).  The
-    // spare workgroups of the per-view dot sit behind all of them.
+    // One launch index, decoded by block_and_view: the V workgroups that read the same 256 Gaussians run back to back on one XCD
+    // (round 2's view-fastest order: config 4 516 -> 484 us; all views on ONE XCD: another 1 %).  The same order makes
+    // k_preprocess SLOWER (210 -> 290 us, measured in rounds 2 and 3) and is not used there.  The spare workgroups of the
+    // per-view dot sit behind all of them.
     const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
     const uint32_t n_pv = gaussian_grid(kp.P, kp.V);
     const bool spare = blockIdx.x >= n_pv;
@@ -2081,6 +2089,97 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
     }
 }
 
+// The same for the case that matters (degree 3, M = 16: BASELINE config 4), built around how the coefficient rows travel.  Above,
+// every lane fetches its own 192-byte row with twelve 16-byte loads: one load instruction touches 64 different cache lines, the
+// rows of all resident waves (240 KB per CU) do not survive in the 32 KB L1 from one load to the next, and every view fetches
+// them again.  Here a workgroup takes its 256 rows ONCE, as one contiguous 48 KiB stream (16 bytes per lane, consecutive lanes
+// consecutive addresses), turns them through LDS into one row per lane held in registers, and then serves T4D_SHB_VIEWS views
+// from them; the staging area is reused for the basis / dL/dcolour exchange of the write-out.
+#ifndef T4D_SHB_VIEWS
+#define T4D_SHB_VIEWS 8
+#endif
+__global__ __launch_bounds__(kBlock) void k_sh_bwd16(const KP kp)
+{
+    constexpr int kPitch = 52;                           // floats per staged row: 16-byte aligned, 13 (odd) 16-byte words -> no bank conflicts
+    __shared__ __attribute__((aligned(16))) float s_raw[kBlock * kPitch];
+    float (*s_bas)[17] = reinterpret_cast<float (*)[17]>(s_raw);                   // after the staging: basis (odd pitch) ...
+    float (*s_gc)[4] = reinterpret_cast<float (*)[4]>(s_raw + kBlock * 17);        // ... and masked dL/dcolour
+    static_assert(kBlock * 17 + kBlock * 4 <= kBlock * kPitch && (kBlock * 17) % 4 == 0, "the exchange arrays live inside the staging area");
+    const int tid = threadIdx.x;
+    const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
+    const uint32_t ngroups = (uint32_t)(kp.V + T4D_SHB_VIEWS - 1) / T4D_SHB_VIEWS;
+    uint32_t pblock, vgrp;
+    if (!block_and_view(blockIdx.x, ngroups, nblocks, pblock, vgrp)) return;
+    const int g0 = (int)pblock * kBlock;
+    const int n = min(kBlock, kp.P - g0);                // Gaussians of this workgroup
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(kp.shs + (size_t)g0 * 48);
+        for (int i = tid; i < n * 12; i += kBlock) {
+            const int r = i / 12, part = i - r * 12;
+            *reinterpret_cast<float4 *>(s_raw + r * kPitch + part * 4) = src[i];
+        }
+    }
+    __syncthreads();
+    float c[48];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(s_raw + min(tid, n - 1) * kPitch + 4 * i);
+        c[4 * i] = t4.x; c[4 * i + 1] = t4.y; c[4 * i + 2] = t4.z; c[4 * i + 3] = t4.w;
+    }
+    __syncthreads();                                     // the rows are in registers: the staging area is free
+    const int g = g0 + min(tid, n - 1);
+    const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+    const bool truncated = kp.status->overflow != 0u;   // a truncated forward (arena overflow without T4D_FLAG_CHECKED): zero gradients
+    const int v_end = min(kp.V, (int)(vgrp + 1u) * T4D_SHB_VIEWS);
+    for (int v = (int)vgrp * T4D_SHB_VIEWS; v < v_end; v++) {
+        // ---- 1. per Gaussian: direction, basis, masked dL/dcolour, the view-direction term of dL/dmeans3D
+        if (tid < n) {
+            const size_t vg = (size_t)v * kp.P + g;
+            const bool vis = !truncated && kp.radii[vg] > 0;
+            float gc[3] = { 0.f, 0.f, 0.f };
+            float bas[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) bas[i] = 0.f;
+            if (vis) {
+                const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
+                const float d0[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
+                const float len = sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+                const float d[3] = { d0[0] / len, d0[1] / len, d0[2] / len };
+                float bx[16], by[16], bz[16];
+                sh_basis(3, d, bas);
+                sh_basis_grad(3, d, bx, by, bz);
+                const uint32_t cl = kp.clamped[vg];                               // channels the forward clamped at zero carry no gradient
+                const float *grgb = kp.dL_dcolors + vg * 3;                       // the pair sums, left here by k_preprocess_bwd
+                gc[0] = (cl & 1u) ? 0.f : grgb[0]; gc[1] = (cl & 2u) ? 0.f : grgb[1]; gc[2] = (cl & 4u) ? 0.f : grgb[2];
+                float gd[3] = { 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const float t = c[3 * k] * gc[0] + c[3 * k + 1] * gc[1] + c[3 * k + 2] * gc[2];
+                    gd[0] += bx[k] * t; gd[1] += by[k] * t; gd[2] += bz[k] * t;
+                }
+                const float dot = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];     // the direction was normalised: project its gradient
+                float *gm = kp.dL_dmeans3D + vg * 3;
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) gm[jj] += (gd[jj] - d[jj] * dot) / len;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) s_bas[tid][i] = bas[i];
+            s_gc[tid][0] = gc[0]; s_gc[tid][1] = gc[1]; s_gc[tid][2] = gc[2];
+        }
+        __syncthreads();
+        // ---- 2. dL/dshs of this view, as one contiguous stream
+        float4 *out4 = reinterpret_cast<float4 *>(kp.dL_dshs + ((size_t)v * kp.P + g0) * 48);
+        for (int i = tid; i < n * 12; i += kBlock) {
+            const int slot = i / 12, e0 = (i - slot * 12) * 4;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = s_bas[slot][(e0 + e) / 3] * s_gc[slot][(e0 + e) % 3];
+            out4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();                                 // the exchange arrays are rewritten by the next view
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // per-view scalar <a, b> (e.g. the loss term sum(colour * dL/dcolour) each rank contributes to the loss gather):
 // one pass over both images, deterministic two-level sum.
@@ -2340,7 +2439,6 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     kp.out_color = io->out_color; kp.out_depth = io->out_depth; kp.out_alpha = io->out_alpha; kp.radii = io->out_radii;
 
     T4D_HIP(hipMemsetAsync(st, 0, L.zero_end, stream));
-    const dim3 gP((p.P + kBlock - 1) / kBlock, p.n_views);
     { ProfScope ps_(stream, K_PREPROCESS);
     hipLaunchKernelGGL(k_preprocess, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
     }
@@ -2367,7 +2465,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         T4D_HIP(hipMemcpyAsync((void *)status, st + L.status, 16, hipMemcpyDeviceToHost, stream));     // the documented 16 bytes
     }
     { ProfScope ps_(stream, K_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(gP.x + (kp.T + kBlock - 1) / kBlock, p.n_views), dim3(kBlock), 0, stream, kp);
+    hipLaunchKernelGGL(k_scatter, dim3(gaussian_grid(p.P, p.n_views) + (unsigned)(((size_t)kp.T * p.n_views + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_scatter");
     { ProfScope ps_(stream, K_SORT_TILES);
@@ -2381,6 +2479,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 6, 2));
     kp.fill_blocks = (uint32_t)(kp.gy * p.n_views);
     kp.fill_vec = (p.W % 4 == 0 && (((uintptr_t)io->out_color | (uintptr_t)io->out_depth | (uintptr_t)io->out_alpha) & 15u) == 0) ? 1u : 0u;
+    if (getenv("T4D_FILL_SCALAR")) kp.fill_vec = 0u;       // tests: the 4-byte path on images that would take the 16-byte one
     if (lat) hipLaunchKernelGGL(k_render_fwd<true>, dim3(kp.tile_blocks + kp.fill_blocks), dim3(kBlock), 0, stream, kp);
     else hipLaunchKernelGGL(k_render_fwd<false>, dim3(kp.tile_blocks + kp.fill_blocks), dim3(kBlock), 0, stream, kp);
     }
@@ -2449,7 +2548,13 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
         kp.dL_dcolors = (float *)((char *)io->scratch + grad_pair_bytes(p) + tile_dot_bytes(p, (size_t)kp.T));
     hipLaunchKernelGGL(k_preprocess_bwd, pgrid, dim3(kBlock), 0, stream, kp);
     if (kp.shs)
-        hipLaunchKernelGGL(k_sh_bwd, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
+    {
+        static const bool plain = getenv("T4D_SH_BWD_PLAIN") != nullptr;         // experiments: the general kernel also for degree 3
+        if (kp.M == 16 && kp.deg == 3 && !plain)
+            hipLaunchKernelGGL(k_sh_bwd16, dim3(gaussian_grid(p.P, (p.n_views + T4D_SHB_VIEWS - 1) / T4D_SHB_VIEWS)), dim3(kBlock), 0, stream, kp);
+        else
+            hipLaunchKernelGGL(k_sh_bwd, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
+    }
     }
     T4D_LAUNCH_CHECK("k_preprocess_bwd");
     return T4D_OK;
