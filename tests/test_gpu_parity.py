@@ -485,3 +485,29 @@ def test_empty_tiles_written_by_row_fill_workgroups(monkeypatch):
             for k in ("color", "depth", "alpha"):
                 assert np.array_equal(outs[0][k], outs[1][k]), k
     monkeypatch.delenv("T4D_FILL_SCALAR", raising=False)
+
+
+def test_sh_backward_degree3_kernel_equals_the_general_one(monkeypatch):
+    """Degree 3 with 16 stored coefficients takes k_sh_bwd16 (coefficient rows staged once per workgroup and EIGHT views, launch
+    index decoded into (block of 256 Gaussians, group of views)); any other layout takes k_sh_bwd.  Both do the same arithmetic
+    in the same order: on 11 views (a full group + one of three) of 384 Gaussians (a full block + half a block) every
+    gradient must be bit-identical, and the general kernel is held to the oracle by test_sh_colour_path."""
+    H = W = 48
+    V = 11
+    rv, cams = util.make_scene(16, 24, H, W, V, opacity="B", sh_degree=3, seed=11)
+    rv["shs"][::5, 0, :] = -3.0
+    from scaffold import scene
+    dc, _, _ = scene.output_cotangents(V, H, W, seed=12)
+    monkeypatch.delenv("T4D_SH_BWD_PLAIN", raising=False)
+    _, g16, _ = util.hip_render(cams, rv, dc)
+    monkeypatch.setenv("T4D_SH_BWD_PLAIN", "1")
+    _, gpl, _ = util.hip_render(cams, rv, dc)
+    monkeypatch.delenv("T4D_SH_BWD_PLAIN", raising=False)
+    assert np.abs(g16["shs"]).max() > 0
+    for k in ("shs", "means2D", "opacities", "scales", "rotations"):
+        assert np.array_equal(g16[k], gpl[k]), k
+    # the view-direction term of dL/dmeans3D: the degree is a compile-time constant in one kernel and a run-time value in the
+    # other, so the basis gradient is contracted differently - last bits only
+    assert np.abs(g16["means3D"] - gpl["means3D"]).max() <= 1e-6 * np.abs(gpl["means3D"]).max()
+    r, g = util.c_oracle_render(cams[9], rv, dc[9])
+    check_grads(g16, g, 9, keys=("means3D", "shs"))
