@@ -57,9 +57,9 @@ namespace {
 #endif
 constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave64)
 #ifndef T4D_FWD_BATCH
-#define T4D_FWD_BATCH 256
+#define T4D_FWD_BATCH 192
 #endif
-constexpr int kFwdBatch = T4D_FWD_BATCH;   // splats staged in LDS per round of the forward blend (one per thread: <= 256)
+constexpr int kFwdBatch = T4D_FWD_BATCH;   // splats staged in LDS per round of the forward blend (one per thread: <= 256; sweep of round 3 with 7 waves per SIMD, config 2 / config 4: 128: 106 / 1,197 us, 192: 101.5 / 1,113, 256: 102 / 1,134)
 #ifndef T4D_BWD_BATCH
 #define T4D_BWD_BATCH 128
 #endif
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t
 }
 
 #ifndef T4D_FWD_WAVES
-#define T4D_FWD_WAVES 6          // 80 VGPRs, no spills; 7 waves (72 VGPRs) spill inside the batch loop and measure 5 % slower
+#define T4D_FWD_WAVES 7          // 72 VGPRs (round 3, after the staging part shrank: 6 waves 105.6 us, 7 waves 101.6 us at config 2; 8 waves spill: 117 us)
 #endif
 // Two instantiations of each per-tile render kernel.  LAT = false is the THROUGHPUT build (many tiles in flight, bound by
 // vector-ALU issue: registers are capped for occupancy, steps go four at a time).  LAT = true is the LATENCY build, chosen by
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     constexpr int kChunks = kFwdBatch / 64;
     constexpr int kListStride = kFwdBatch + 8;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
     constexpr int kRec = 48;                         // bytes per staged splat: xy, cut-off r2 (12, +4 pad) | scaled conic + opacity | rgb + depth
-    static_assert(kFwdBatch == kBlock, "every thread stages one slot per batch (and clears it when the list is shorter)");
+    static_assert(kFwdBatch <= kBlock && kFwdBatch % 64 == 0, "one staging thread per slot (it clears the slot when the list is shorter)");
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFwdBatch + 1) * kRec];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     __shared__ uint32_t s_wave_done[4];
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             __syncthreads();                         // (also: everyone has left the previous batch's records)
             if ((s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) != 0u) break;
         }
-        {
+        if (kFwdBatch == kBlock || tid < kFwdBatch) {
             float4 head = make_float4(0.f, 0.f, -1.f, 0.f);      // (x, y, cut-off r2, -): a slot without a splat touches nothing
             if (b + tid < n) {
                 const unsigned long long key = keys[b + tid];
@@ -2549,7 +2549,7 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     hipLaunchKernelGGL(k_preprocess_bwd, pgrid, dim3(kBlock), 0, stream, kp);
     if (kp.shs)
     {
-        static const bool plain = getenv("T4D_SH_BWD_PLAIN") != nullptr;         // experiments: the general kernel also for degree 3
+        const bool plain = getenv("T4D_SH_BWD_PLAIN") != nullptr;                // tests / experiments: the general kernel also for degree 3
         if (kp.M == 16 && kp.deg == 3 && !plain)
             hipLaunchKernelGGL(k_sh_bwd16, dim3(gaussian_grid(p.P, (p.n_views + T4D_SHB_VIEWS - 1) / T4D_SHB_VIEWS)), dim3(kBlock), 0, stream, kp);
         else
