@@ -511,3 +511,40 @@ def test_sh_backward_degree3_kernel_equals_the_general_one(monkeypatch):
     assert np.abs(g16["means3D"] - gpl["means3D"]).max() <= 1e-6 * np.abs(gpl["means3D"]).max()
     r, g = util.c_oracle_render(cams[9], rv, dc[9])
     check_grads(g16, g, 9, keys=("means3D", "shs"))
+
+
+def test_one_view_scan_and_scatter_in_one_launch(monkeypatch):
+    """One view of at most 1,024 tiles (Topo4D's own call shape) runs k_scan_scatter_small instead of k_scan_tiles + k_scatter.
+    Everything the two kernels leave behind must be identical: tile offsets, the view's total, the status block, the sorted keys
+    of every tile, the outputs and the gradients; the work items may come in another order inside a length class (both orders
+    are arbitrary), so they are compared as sets per class.  Sizes: 512x375 with Topo4D's 8,280 Gaussians, a 1,024-tile
+    image, and a tiny one."""
+    from scaffold import scene
+    for (n_lat, n_lon, H, W) in ((69, 120, 512, 375), (40, 60, 512, 512), (6, 8, 33, 90)):
+        rv, cams = util.make_scene(n_lat, n_lon, H, W, 24 if H > 100 else 3, opacity="A", seed=3)
+        cams = cams[len(cams) // 2: len(cams) // 2 + 1]
+        dc, _, _ = scene.output_cotangents(1, H, W, seed=4)
+        res = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("T4D_NO_SMALL_VIEW", "1")
+            else:
+                monkeypatch.delenv("T4D_NO_SMALL_VIEW", raising=False)
+            hip, hg, batch = util.hip_render(cams, rv, dc)
+            st = util.decode_state(batch)
+            res.append((hip, hg, st, batch.last_status))
+        monkeypatch.delenv("T4D_NO_SMALL_VIEW", raising=False)
+        (h0, g0, s0, t0), (h1, g1, s1, t1) = res
+        assert (t0.max_pairs_per_view, t0.total_pairs, t0.overflow, t0.max_tile_pairs) == \
+               (t1.max_pairs_per_view, t1.total_pairs, t1.overflow, t1.max_tile_pairs)
+        for k in ("tile_count", "tile_off", "view_total", "bucket_fill"):
+            assert np.array_equal(s0[k], s1[k]), k
+        tc, to = s0["tile_count"][0], s0["tile_off"][0]
+        for t in np.nonzero(tc)[0]:
+            assert np.array_equal(s0["keys"][0][to[t]:to[t] + tc[t]], s1["keys"][0][to[t]:to[t] + tc[t]]), int(t)
+        for k in ("color", "depth", "alpha", "radii"):
+            assert np.array_equal(h0[k], h1[k]), k
+        for k in util.GRAD_KEYS:
+            assert np.array_equal(g0[k], g1[k]), k
+        r, g = util.c_oracle_render(cams[0], rv, dc[0])
+        check_outputs(h0, r.color, r.depth, r.alpha, 0, max_flips=2)

@@ -101,7 +101,7 @@ def decode_state(batch):
     n_contrib = np.where(empty, np.uint32(0), f("n_contrib", V * H * W, np.uint32).reshape(V, H, W))
     return dict(
         status=f("status", 4, np.uint32), view_total=f("view_total", V, np.uint32),
-        tile_count=tile_count,
+        tile_count=tile_count, bucket_fill=f("bucket_fill", 24, np.uint32),
         tile_off=f("tile_off", V * T, np.uint32).reshape(V, T),
         xy=f("xy", V * P * 2, np.float32).reshape(V, P, 2), depth=f("depth", V * P, np.float32).reshape(V, P),
         conic_opacity=f("conic_opacity", V * P * 4, np.float32).reshape(V, P, 4),

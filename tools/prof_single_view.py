@@ -22,5 +22,6 @@ torch.cuda.synchronize()
 prof = _lib.profile_end()
 tot = 0.0
 for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+    if n == 0: continue                      # (one view of <= 1,024 tiles: the scan is part of the scatter launch)
     print(f"{name:24s} {1000 * ms / n:8.1f} us  x{n // 200}/iter"); tot += 1000 * ms / 200
 print(f"sum of kernels {tot:.1f} us per iteration; pairs {b.fetch_status().total_pairs}")

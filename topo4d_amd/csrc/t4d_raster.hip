@@ -715,6 +715,105 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// A.2 for ONE view of at most 1,024 tiles (the reference's own call shape: train.py:661-673 renders one 512x375 view = 768
+// tiles per iteration): scan and scatter in one launch.  A launch that small is made of kernel boundaries, not of work -
+// k_scan_tiles lasts 6.7 us there for 768 additions - and nothing in the scan needs another workgroup: every scatter
+// workgroup adds up the view's tile counts itself (four per thread, in LDS) and takes its offsets from there; one extra
+// workgroup does what else the scan kernel leaves behind - the offsets in memory, the view's total, the status block and
+// the length-ordered work items (built in LDS: a single workgroup sees every tile, so the per-class lists of k_scan_tiles
+// and the flattening pass of k_scatter are not needed).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSmallTiles = 4 * kBlock;
+
+__global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
+{
+    __shared__ uint32_t s_off[kSmallTiles];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_bcnt[kBuckets], s_bpre[kBuckets];
+    __shared__ uint32_t s_longest[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // ---- exclusive scan of the tile counts: thread t owns tiles 4t .. 4t + 3
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = 4 * tid + j < kp.T ? kp.tile_count[4 * tid + j] : 0u;
+    const uint32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+    const uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63) s_wtot[wave] = incl;
+    if (tid < kBuckets) s_bcnt[tid] = 0;
+    __syncthreads();
+    uint32_t base = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t x = s_wtot[w];
+        if (w < wave) base += x;
+        total += x;
+    }
+    uint32_t off[4];
+    off[0] = base; off[1] = off[0] + c[0]; off[2] = off[1] + c[1]; off[3] = off[2] + c[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_off[4 * tid + j] = off[j];
+    const uint32_t nb8 = gaussian_grid(kp.P, 1);
+    if (blockIdx.x == nb8) {
+        // ---- the scan kernel's other products, and the work items
+        uint32_t longest = max(max(c[0], c[1]), max(c[2], c[3]));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
+        if (lane == 0) s_longest[wave] = longest;
+        int bk[4];
+        uint32_t rank[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bk[j] = count_bucket(c[j]);
+            rank[j] = 4 * tid + j < kp.T ? atomicAdd(&s_bcnt[bk[j]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (int k = 0; k < kBuckets; k++) { s_bpre[k] = acc; acc += s_bcnt[k]; }
+        }
+        __syncthreads();
+        if (tid < kBuckets) kp.bucket_fill[tid] = s_bcnt[tid];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = 4 * tid + j;
+            if (t < kp.T) {
+                kp.tile_off[t] = off[j];
+                const uint32_t n = off[j] >= kp.cap ? 0u : min(c[j], kp.cap - off[j]);
+                kp.items[s_bpre[bk[j]] + rank[j]] = make_uint4((uint32_t)t, off[j], n, c[j]);       // view 0: id = tile
+            }
+        }
+        if (tid == 0) {
+            kp.view_total[0] = total;
+            uint32_t fill = 0;                                  // fullest pair-slot segment (see k_scan_tiles)
+            for (uint32_t k = 0; k < kp.nseg; k++) fill = max(fill, kp.view_cursor[k]);
+            const unsigned long long need = max((unsigned long long)total, (unsigned long long)fill * kp.nseg);
+            kp.status->max_pairs = (uint32_t)min(need, 0xffffffffull);
+            kp.status->total_pairs = (unsigned long long)total;
+            kp.status->max_tile_pairs = max(max(s_longest[0], s_longest[1]), max(s_longest[2], s_longest[3]));
+            if (total > kp.cap || fill > kp.seg_cap) kp.status->overflow = 1u;
+        }
+        return;
+    }
+    __syncthreads();
+    // ---- scatter (k_scatter's body on the offsets in LDS)
+    const int g = (int)blockIdx.x * kBlock + tid;
+    if (g >= kp.P) return;
+    const int r = kp.radii[g];
+    if (r <= 0) return;
+    const float2 p = kp.xy[g];
+    int x0, y0, x1, y1;
+    tile_rect(p.x, p.y, r, kp.gx, kp.gy, x0, y0, x1, y1);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(kp.depth[g]) << 32) | (uint32_t)g;
+    uint32_t pr = kp.pair_off[g];
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++, pr++) {
+            if (pr >= kp.cap) return;
+            const uint32_t pos = s_off[y * kp.gx + x] + kp.pair_rank[pr];
+            if (pos < kp.cap) kp.keys[pos] = key;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // A.2 per-tile sort by (depth bits, Gaussian index)
 // ---------------------------------------------------------------------------------------------------------
 // Sort the 64 keys of a wave (one per lane) ascending, entirely in registers: bitonic network whose exchanges are DPP
@@ -1149,12 +1248,14 @@ template <bool LAT>
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
     constexpr int kU = LAT ? 8 : 4;                  // steps per group
-    constexpr int kNull = kFwdBatch;                 // staged slot that can never contribute (opacity 0)
-    constexpr int kChunks = kFwdBatch / 64;
-    constexpr int kListStride = kFwdBatch + 8;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
+    // splats staged per batch: the latency build has the LDS of a whole CU and lives as long as its longest tile - fewer batches
+    constexpr int kFB = LAT ? kBlock : kFwdBatch;
+    constexpr int kNull = kFB;                 // staged slot that can never contribute (opacity 0)
+    constexpr int kChunks = kFB / 64;
+    constexpr int kListStride = kFB + 8;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
     constexpr int kRec = 48;                         // bytes per staged splat: xy, cut-off r2 (12, +4 pad) | scaled conic + opacity | rgb + depth
-    static_assert(kFwdBatch <= kBlock && kFwdBatch % 64 == 0, "one staging thread per slot (it clears the slot when the list is shorter)");
-    __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFwdBatch + 1) * kRec];
+    static_assert(kFB <= kBlock && kFB % 64 == 0, "one staging thread per slot (it clears the slot when the list is shorter)");
+    __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFB + 1) * kRec];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     __shared__ uint32_t s_wave_done[4];
     const int tid = threadIdx.x;
@@ -1187,13 +1288,13 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
-    for (uint32_t b = 0; b < n; b += kFwdBatch) {
+    for (uint32_t b = 0; b < n; b += kFB) {
         if (b != 0) {                                // a further batch: needed only while some pixel of the tile is unfinished
             if (lane == 0) s_wave_done[wave] = done_m == ~0ull ? 1u : 0u;
             __syncthreads();                         // (also: everyone has left the previous batch's records)
             if ((s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) != 0u) break;
         }
-        if (kFwdBatch == kBlock || tid < kFwdBatch) {
+        if (kFB == kBlock || tid < kFB) {
             float4 head = make_float4(0.f, 0.f, -1.f, 0.f);      // (x, y, cut-off r2, -): a slot without a splat touches nothing
             if (b + tid < n) {
                 const unsigned long long key = keys[b + tid];
@@ -2443,9 +2544,15 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     hipLaunchKernelGGL(k_preprocess, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess");
-    { ProfScope ps_(stream, K_SCAN_TILES);
-    if (kp.n_chunks > 1) hipLaunchKernelGGL(k_tile_chunk_sums, dim3(kp.n_chunks, p.n_views), dim3(kScanChunk), 0, stream, kp);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(kp.n_chunks, p.n_views), dim3(kScanChunk), 0, stream, kp);
+    // one view of at most 1,024 tiles (Topo4D's own call shape): scan and scatter are ONE launch (k_scan_scatter_small)
+    const bool small_view = p.n_views == 1 && kp.T <= kSmallTiles && getenv("T4D_NO_SMALL_VIEW") == nullptr;
+    if (small_view) {
+        ProfScope ps_(stream, K_SCATTER);
+        hipLaunchKernelGGL(k_scan_scatter_small, dim3(gaussian_grid(p.P, 1) + 1), dim3(kBlock), 0, stream, kp);
+    } else {
+        ProfScope ps_(stream, K_SCAN_TILES);
+        if (kp.n_chunks > 1) hipLaunchKernelGGL(k_tile_chunk_sums, dim3(kp.n_chunks, p.n_views), dim3(kScanChunk), 0, stream, kp);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(kp.n_chunks, p.n_views), dim3(kScanChunk), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_scan_tiles");
     if (checked) {
@@ -2464,8 +2571,9 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         // has run; the caller looks at it after an event of its own (topo4d_amd's "auto" sync mode does, one call later)
         T4D_HIP(hipMemcpyAsync((void *)status, st + L.status, 16, hipMemcpyDeviceToHost, stream));     // the documented 16 bytes
     }
-    { ProfScope ps_(stream, K_SCATTER);
-    hipLaunchKernelGGL(k_scatter, dim3(gaussian_grid(p.P, p.n_views) + (unsigned)(((size_t)kp.T * p.n_views + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, kp);
+    if (!small_view) {
+        ProfScope ps_(stream, K_SCATTER);
+        hipLaunchKernelGGL(k_scatter, dim3(gaussian_grid(p.P, p.n_views) + (unsigned)(((size_t)kp.T * p.n_views + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_scatter");
     { ProfScope ps_(stream, K_SORT_TILES);
