@@ -1670,22 +1670,33 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         if (tid < kChunks * 64) {
             float r2 = -1.f;                                 // a slot without a splat touches nothing ...
             float2 p = make_float2(0.f, 0.f);                // ... and holds a finite centre
-            if (tid < cnt && (uint32_t)keys[lo + tid] < (uint32_t)kp.P) {     // stale entries after an overflow are skipped
+            if (tid < cnt) {
+                // ONE level of dependent loads behind the key: everything a splat needs is requested before any of it is used
+                // (as the code was written - centre and radius, then the pair slot, then conic and colour - the staging waves went
+                // through four dependent round trips per batch while the other waves waited at the barrier)
                 const unsigned long long key = keys[lo + tid];
+                const float r2_kept = live ? r2_in[lo + tid] : -1.f;               // = cutoff_radius2(c), kept by the forward
                 const uint32_t g = (uint32_t)key;
-                p = xy[g];
-                int x0, y0, x1, y1;
-                tile_rect(p.x, p.y, radii[g], kp.gx, kp.gy, x0, y0, x1, y1);
-                const int local = (ty - y0) * (x1 - x0) + (tx - x0);
-                s_pair[tid] = (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) ? pair_off[g] + (uint32_t)local : 0xffffffffu;
-                if (live) {
-                    const float4 c = co[g];
-                    const float4 q4 = scale_conic(c);
-                    float2 *rec = reinterpret_cast<float2 *>(s_rec + tid * kEnt);
-                    rec[0] = make_float2(q4.x, q4.y); rec[1] = make_float2(q4.z, q4.w);
-                    rec[2] = make_float2(rgb[3 * (size_t)g], rgb[3 * (size_t)g + 1]);
-                    rec[3] = make_float2(rgb[3 * (size_t)g + 2], __uint_as_float((uint32_t)(key >> 32)));
-                    r2 = r2_in[lo + tid];                    // = cutoff_radius2(c), kept by the forward
+                if (g < (uint32_t)kp.P) {                                          // stale entries after an overflow are skipped
+                    const float2 pg = xy[g];
+                    const int rad = radii[g];
+                    const uint32_t po = pair_off[g];
+                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                    if (live) { c = co[g]; c0 = rgb[3 * (size_t)g]; c1 = rgb[3 * (size_t)g + 1]; c2 = rgb[3 * (size_t)g + 2]; }
+                    p = pg;
+                    int x0, y0, x1, y1;
+                    tile_rect(pg.x, pg.y, rad, kp.gx, kp.gy, x0, y0, x1, y1);
+                    const int local = (ty - y0) * (x1 - x0) + (tx - x0);
+                    s_pair[tid] = (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) ? po + (uint32_t)local : 0xffffffffu;
+                    if (live) {
+                        const float4 q4 = scale_conic(c);
+                        float2 *rec = reinterpret_cast<float2 *>(s_rec + tid * kEnt);
+                        rec[0] = make_float2(q4.x, q4.y); rec[1] = make_float2(q4.z, q4.w);
+                        rec[2] = make_float2(c0, c1);
+                        rec[3] = make_float2(c2, __uint_as_float((uint32_t)(key >> 32)));
+                        r2 = r2_kept;
+                    }
                 }
             }
             if (live) {
