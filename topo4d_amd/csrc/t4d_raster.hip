@@ -189,6 +189,26 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
     y1 = min(gy, max(0, (int)((py + r + T4D_TILE_Y - 1) / T4D_TILE_Y)));
 }
 
+// A view's camera record, read through the CONSTANT address space: the record is the same for every lane of a workgroup, and
+// only loads from memory the compiler knows to be read-only become scalar loads (s_load_dwordx16 into SGPRs).  Through a plain
+// pointer the 40 floats came as per-lane vector loads: 32 vector registers for two matrices every lane holds identically, and
+// one more level in the per-Gaussian kernels' chains of dependent loads.
+typedef const __attribute__((address_space(4))) float *const_float_p;
+struct ViewRecord {
+    float view[16], proj[16], campos[3], bg[3], tanx, tany;
+};
+__device__ __forceinline__ ViewRecord load_view_record(const float *views, const int v)
+{
+    const_float_p p = (const_float_p)(views + (size_t)v * T4D_VIEW_FLOATS);
+    ViewRecord r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { r.view[i] = p[i]; r.proj[i] = p[16 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { r.campos[i] = p[32 + i]; r.bg[i] = p[35 + i]; }
+    r.tanx = p[38]; r.tany = p[39];
+    return r;
+}
+
 // wave64 inclusive prefix sum (uint32)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -373,8 +393,8 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
 #endif
     const int g = (int)gb * kBlock + tid;
     const int v = (int)vb;
-    const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
-    const float *view = vr, *proj = vr + 16;
+    const ViewRecord vrec = load_view_record(kp.views, v);
+    const float *view = vrec.view, *proj = vrec.proj;
     const size_t vg = (size_t)v * kp.P + g;
 
     uint32_t tiles = 0;
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                 const float4 q = reinterpret_cast<const float4 *>(kp.rotations)[g];
                 cov3d_from_scale_rot(sc, kp.scale_modifier, q, cov3);
             }
-            const float tanx = vr[38], tany = vr[39];
+            const float tanx = vrec.tanx, tany = vrec.tany;
             const float fx = kp.W / (2.0f * tanx), fy = kp.H / (2.0f * tany);
             float T0[3], T1[3], t[3];
             bool inx, iny;
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                     kp.depth[vg] = pvz;
                     kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, kp.opacities[g]);
                     if (kp.shs && T4D_ABL != 8) {
-                        float d[3] = { mean[0] - vr[32], mean[1] - vr[33], mean[2] - vr[34] };
+                        float d[3] = { mean[0] - vrec.campos[0], mean[1] - vrec.campos[1], mean[2] - vrec.campos[2] };
                         const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
                         d[0] /= len; d[1] /= len; d[2] /= len;
                         float bas[16];
@@ -1953,12 +1973,31 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
     }
     if (g >= kp.P) return;
     const size_t vg = (size_t)v * kp.P + g;
-    const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
-    const float *view = vr, *proj = vr + 16;
+    const ViewRecord vrec = load_view_record(kp.views, v);
+    const float *view = vrec.view, *proj = vrec.proj;
+    // Everything that depends on (view, Gaussian) alone is requested HERE, before any of it is used: as the kernel was written
+    // (radius, then centre, then pair slot, then the records, then conic and mean, then scale and rotation) a thread went through
+    // eight dependent round trips, and the kernel is made of those (a quarter of the vector ALUs busy).
+    const uint32_t flag = kp.status->overflow;
+    const int radius_in = kp.radii[vg];
+    const float2 p2 = kp.xy[vg];
+    const uint32_t base = kp.pair_off[vg];
+    const float4 cq = kp.conic_opacity[vg];
+    const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+    float cov3_in[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+    float sc[3] = { 0.f, 0.f, 0.f };
+    if (kp.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov3_in[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+    } else {
+        sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
+        q = reinterpret_cast<const float4 *>(kp.rotations)[g];
+    }
     // A forward whose pair arena overflowed (possible only without T4D_FLAG_CHECKED) left tile lists truncated and pair
     // records unwritten: its backward returns ZERO gradients for every view instead of sums over uninitialised scratch.
-    const bool truncated = kp.status->overflow != 0u;
-    const int radius = truncated ? 0 : kp.radii[vg];
+    const bool truncated = flag != 0u;
+    const int radius = truncated ? 0 : radius_in;
 
     float gm[3] = { 0.f, 0.f, 0.f }, g2x = 0.f, g2y = 0.f, gop = 0.f;
     float grgb[3] = { 0.f, 0.f, 0.f }, gsc[3] = { 0.f, 0.f, 0.f }, gq[4] = { 0.f, 0.f, 0.f, 0.f };
@@ -1966,11 +2005,9 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
 
     if (radius > 0) {
         // ---- gather the partial gradients of this Gaussian's tiles ----
-        const float2 p2 = kp.xy[vg];
         int x0, y0, x1, y1;
         tile_rect(p2.x, p2.y, radius, kp.gx, kp.gy, x0, y0, x1, y1);
         const uint32_t npairs = (uint32_t)((x1 - x0) * (y1 - y0));
-        const uint32_t base = kp.pair_off[vg];
         const float2 *gp = reinterpret_cast<const float2 *>(kp.grad_pair) + (size_t)v * kp.cap * (kGP / 2);
         float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, gdep = 0.f;
         for (uint32_t k = 0; k < npairs; k++) {
@@ -1983,25 +2020,19 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
             grgb[2] += a4.x; gdep += a4.y;
         }
         // per-splat constants applied once (see k_render_bwd): dL/dG = opacity * dL/dalpha, dG/dd = -G * conic * d
-        const float4 cq = kp.conic_opacity[vg];
         gop = S0;
         g2x = -cq.w * (cq.x * S1 + cq.y * S2) * (0.5f * kp.W);
         g2y = -cq.w * (cq.z * S2 + cq.y * S1) * (0.5f * kp.H);
         const float X = -0.5f * cq.w * S3, Y = -cq.w * S4, Z = -0.5f * cq.w * S5;      // true d/d(conic A, B, C)
 
-        const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
         float cov3[6];
-        float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
-        float sc[3] = { 0.f, 0.f, 0.f };
         if (kp.cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) cov3[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+            for (int k = 0; k < 6; k++) cov3[k] = cov3_in[k];
         } else {
-            sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
-            q = reinterpret_cast<const float4 *>(kp.rotations)[g];
             cov3d_from_scale_rot(sc, kp.scale_modifier, q, cov3);
         }
-        const float tanx = vr[38], tany = vr[39];
+        const float tanx = vrec.tanx, tany = vrec.tany;
         const float fx = kp.W / (2.0f * tanx), fy = kp.H / (2.0f * tany);
         float T0[3], T1[3], t[3];
         bool inx, iny;
