@@ -401,6 +401,17 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (g < kp.P) {
         const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+        // (covariance parameters and opacity are requested together with the mean, not behind the near-plane test)
+        float cov3_in[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, sc[3] = { 0.f, 0.f, 0.f };
+        float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (kp.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov3_in[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+        } else {
+            sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
+            q = reinterpret_cast<const float4 *>(kp.rotations)[g];
+        }
+        const float opacity = kp.opacities[g];
         int radius = 0;
         const float pvz = view[2] * mean[0] + view[6] * mean[1] + view[10] * mean[2] + view[14];
         if (pvz > T4D_NEAR_CULL_Z) {
@@ -411,10 +422,8 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
             float cov3[6];
             if (kp.cov3D_precomp) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) cov3[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+                for (int k = 0; k < 6; k++) cov3[k] = cov3_in[k];
             } else {
-                const float sc[3] = { kp.scales[3 * (size_t)g], kp.scales[3 * (size_t)g + 1], kp.scales[3 * (size_t)g + 2] };
-                const float4 q = reinterpret_cast<const float4 *>(kp.rotations)[g];
                 cov3d_from_scale_rot(sc, kp.scale_modifier, q, cov3);
             }
             const float tanx = vrec.tanx, tany = vrec.tany;
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                     radius = (int)my_radius;
                     kp.xy[vg] = make_float2(px, py);
                     kp.depth[vg] = pvz;
-                    kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, kp.opacities[g]);
+                    kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacity);
                     if (kp.shs && T4D_ABL != 8) {
                         float d[3] = { mean[0] - vrec.campos[0], mean[1] - vrec.campos[1], mean[2] - vrec.campos[2] };
                         const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -717,15 +726,16 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
     if (g >= kp.P) return;
     const size_t vg = (size_t)v * kp.P + g;
     const int r = kp.radii[vg];
+    const float2 p = kp.xy[vg];                      // (requested with the radius, not behind it: one round trip less)
+    const float dep = kp.depth[vg];
+    uint32_t pr = kp.pair_off[vg];
     if (r <= 0) return;
-    const float2 p = kp.xy[vg];
     int x0, y0, x1, y1;
     tile_rect(p.x, p.y, r, kp.gx, kp.gy, x0, y0, x1, y1);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(kp.depth[vg]) << 32) | (uint32_t)g;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dep) << 32) | (uint32_t)g;
     const uint32_t *off = kp.tile_off + (size_t)v * kp.T;
     const uint32_t *prank = kp.pair_rank + (size_t)v * kp.cap;
     unsigned long long *keys = kp.keys + (size_t)v * kp.cap;
-    uint32_t pr = kp.pair_off[vg];
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++, pr++) {
             if (pr >= kp.cap) return;
@@ -819,12 +829,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
     const int g = (int)blockIdx.x * kBlock + tid;
     if (g >= kp.P) return;
     const int r = kp.radii[g];
-    if (r <= 0) return;
     const float2 p = kp.xy[g];
+    const float dep = kp.depth[g];
+    uint32_t pr = kp.pair_off[g];
+    if (r <= 0) return;
     int x0, y0, x1, y1;
     tile_rect(p.x, p.y, r, kp.gx, kp.gy, x0, y0, x1, y1);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(kp.depth[g]) << 32) | (uint32_t)g;
-    uint32_t pr = kp.pair_off[g];
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dep) << 32) | (uint32_t)g;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++, pr++) {
             if (pr >= kp.cap) return;
