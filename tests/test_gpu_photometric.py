@@ -110,3 +110,27 @@ def test_masked_l1_matches_reference_golden_g8_and_torch():
         np.testing.assert_allclose(a.grad[v].cpu().numpy(), ref_in.grad.numpy(), rtol=1e-5, atol=1e-12)
     assert torch.isnan(lb[2]) and not a.grad[2].any()
     assert torch.equal(loss.masked_l1_loss(a, gtb.cuda(), mask.cuda())[:2], lb[:2])            # deterministic
+
+
+@pytest.mark.parametrize("shape", [(1, 512, 375), (2, 97, 210), (24, 128, 128)])
+def test_two_wave_roles_equal_one_thread_per_column(shape, monkeypatch):
+    """k_photo_split (single views: first-stage waves and second-stage waves per strip) and k_photo_fused (batches: one thread
+    per column for both stages) do the same arithmetic in the same order: loss, dL/dim and the camera gradients must be
+    bit-identical whichever of them the launch picks (T4D_PH_SPLIT forces one)."""
+    V, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    im = torch.rand(V, 3, H, W, generator=g).cuda()
+    gt = (im.cpu() + torch.randn(V, 3, H, W, generator=g) * 0.1).clamp(0, 1).cuda()
+    cm = (torch.randn(V, 3, generator=g) * 0.1).cuda()
+    cc = (torch.randn(V, 3, generator=g) * 0.05).cuda()
+    out = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("T4D_PH_SPLIT", split)
+        a = [t.clone().requires_grad_(True) for t in (im, cm, cc)]
+        l = loss.photometric_loss(a[0], gt, a[1], a[2])
+        l.sum().backward()
+        out.append([l.detach().cpu().numpy()] + [t.grad.cpu().numpy() for t in a])
+    monkeypatch.delenv("T4D_PH_SPLIT", raising=False)
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+    assert np.isfinite(out[0][0]).all() and np.abs(out[0][1]).max() > 0

@@ -250,6 +250,195 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_WAVE
     }
 }
 
+// The same strip, two WAVE ROLES (round 3): threads [0, kFT) run the first stage - inputs, the five filtered maps, SSIM, the
+// adjoint row - and threads [kFT, 2 kFT) the second - the three filtered adjoint maps, dL/dx', the affine backward.  One
+// thread per column held both register windows (55 + 33 values) and their arithmetic: 166 registers, three waves per SIMD,
+// and at 24 x 512^2 only 2,592 waves for 1,024 SIMDs - the vector ALUs were busy 57 % of the kernel (rocprofv3 PMC: 78 M
+// instructions = 128 us of issue in a 237 us kernel; the rest is a wave waiting for its own LDS round trips and barrier).
+// Split by stage a thread needs ~100 / ~70 registers and there are twice as many waves.  The arithmetic, its order and the
+// one barrier per row are unchanged: results are bit-identical to k_photo_fused.  Measured (see the launch below): it pays for
+// a single view, not for a batch - the two stages wait for each other at the row barrier and the first is twice the second.
+#ifndef T4D_PH_SPLIT_WAVES
+#define T4D_PH_SPLIT_WAVES 4
+#endif
+template <int kFT>
+__global__ __launch_bounds__(2 * kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_SPLIT_WAVES, T4D_PH_SPLIT_WAVES))) void k_photo_split(const PhP P)
+{
+    constexpr int kInW = kFT + 2 * kR;
+    __shared__ float2 s_in[2][kInW];
+    __shared__ float2 s_d01[2][kFT + 2 * kR + 2];
+    __shared__ float s_d2[2][kFT + 2 * kR + 2];
+    __shared__ float s_red[8];
+    const bool first = threadIdx.x < kFT;                // wave-uniform: kFT is a multiple of 64
+    const int tid = first ? threadIdx.x : threadIdx.x - kFT;
+    const int vc = blockIdx.z, v = vc / 3;
+    const int xs = blockIdx.x * P.tw, xe = min(xs + P.tw, P.W);
+    const int y0 = blockIdx.y * P.th, y1 = min(y0 + P.th, P.H);
+    const size_t HW = (size_t)P.H * P.W;
+    const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
+    const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
+    const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
+    const float g = -0.2f * wv / N;
+    const float l1w = 0.8f * wv / N;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = P.win[k];
+    for (int b = 0; b < 2; b++) {                        // the first iteration's second stage reads a row nobody wrote
+        if (first) {
+            s_d01[b][tid] = make_float2(0.f, 0.f); s_d2[b][tid] = 0.f;
+            if (tid < 2 * kR + 2) { s_d01[b][kFT + tid] = make_float2(0.f, 0.f); s_d2[b][kFT + tid] = 0.f; }
+        }
+    }
+    const int i_first = y0 - 2 * kR, i_last = y1 + 2 * kR;
+    float sum_l1 = 0.f, sum_s = 0.f, sum_gm = 0.f, sum_gc = 0.f;
+
+    if (first) {
+        // ---------------- first stage ----------------
+        const int gx1 = xs - kR + tid;
+        const bool col1 = gx1 >= 0 && gx1 < P.W;
+        const bool own1 = tid >= kR && gx1 < xe;
+        const int lx0 = xs - 2 * kR + tid, lx1 = lx0 + kFT;
+        const bool l0 = lx0 >= 0 && lx0 < P.W, l1 = tid < 2 * kR && lx1 < P.W;
+        v2f h01[11], h23[11];
+        float h4[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) { h01[k] = h23[k] = (v2f){ 0.f, 0.f }; h4[k] = 0.f; }
+        float pa0 = 0.f, pb0 = 0.f, pa1 = 0.f, pb1 = 0.f;
+        auto fetch = [&](int i) {
+            pa0 = pb0 = pa1 = pb1 = 0.f;
+            if (i >= 0 && i < P.H) {
+                const size_t o = (size_t)i * P.W;
+                if (l0) { pa0 = im[o + lx0]; pb0 = gt[o + lx0]; }
+                if (l1) { pa1 = im[o + lx1]; pb1 = gt[o + lx1]; }
+            }
+        };
+        fetch(i_first);
+        auto row = [&](const int i, auto J_) {
+            constexpr int J = decltype(J_)::value;
+            const int buf = i & 1;
+            {
+                const bool in_img = i >= 0 && i < P.H;
+                s_in[buf][tid] = (in_img && l0) ? make_float2(em * pa0 + cc, pb0) : make_float2(0.f, 0.f);
+                if (tid < 2 * kR) s_in[buf][tid + kFT] = (in_img && l1) ? make_float2(em * pa1 + cc, pb1) : make_float2(0.f, 0.f);
+            }
+            fetch(i + 1);
+            __syncthreads();
+            {
+                v2f a01 = { 0.f, 0.f }, a23 = { 0.f, 0.f };
+                float a4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const v2f ab = *reinterpret_cast<const v2f *>(&s_in[buf][tid + k]);
+                    const v2f wab = w[k] * ab;
+                    a01 += wab;
+                    a23 = __builtin_elementwise_fma(wab, ab, a23);
+                    a4 = fmaf(wab.x, ab.y, a4);
+                }
+                h01[J] = a01; h23[J] = a23; h4[J] = a4;
+            }
+            v2f m12 = { 0.f, 0.f }, eac = { 0.f, 0.f };
+            float eb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const int sl = (J + 1 + k) % 11;
+                const v2f wk = { w[k], w[k] };
+                m12 = __builtin_elementwise_fma(wk, h01[sl], m12);
+                eac = __builtin_elementwise_fma(wk, h23[sl], eac);
+                eb = fmaf(w[k], h4[sl], eb);
+            }
+            const float mu1 = m12.x, mu2 = m12.y, ea = eac.x, ec = eac.y;
+            const int srow = i - kR;
+            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            if (col1 && srow >= 0 && srow < P.H) {
+                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s11 = ea - mu1s, s22 = ec - mu2s, s12 = eb - mu12;
+                const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
+                const float inv = 1.f / (B1 * B2);
+                const float S = A1 * A2 * inv;
+                const float gi = g * inv;
+                d1 = 2.f * gi * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
+                d2 = -gi * S * B1;
+                d3 = 2.f * gi * A1;
+                if (own1 && srow >= y0 && srow < y1) sum_s += S;
+            }
+            s_d01[buf][tid] = make_float2(d1, d2); s_d2[buf][tid] = d3;
+        };
+        for (int base = i_first; base <= i_last; base += 11) {
+            if (base + 0 <= i_last) row(base + 0, IC<0>()); if (base + 1 <= i_last) row(base + 1, IC<1>());
+            if (base + 2 <= i_last) row(base + 2, IC<2>()); if (base + 3 <= i_last) row(base + 3, IC<3>());
+            if (base + 4 <= i_last) row(base + 4, IC<4>()); if (base + 5 <= i_last) row(base + 5, IC<5>());
+            if (base + 6 <= i_last) row(base + 6, IC<6>()); if (base + 7 <= i_last) row(base + 7, IC<7>());
+            if (base + 8 <= i_last) row(base + 8, IC<8>()); if (base + 9 <= i_last) row(base + 9, IC<9>());
+            if (base + 10 <= i_last) row(base + 10, IC<10>());
+        }
+    } else {
+        // ---------------- second stage ----------------
+        const int gx2 = xs + tid;
+        const bool col2 = gx2 < xe;
+        v2f hd01[11];
+        float hd2[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) { hd01[k] = (v2f){ 0.f, 0.f }; hd2[k] = 0.f; }
+        auto row = [&](const int i, auto J_) {
+            constexpr int J = decltype(J_)::value;
+            const int buf = i & 1;
+            // the pixel of the OUTPUT row of this iteration (eleven rows behind): needed at the very end, requested now
+            const int o_row = i - 2 * kR - 1;
+            const bool emit = col2 && o_row >= y0 && o_row < y1;
+            float o_im = 0.f, o_gt = 0.f;
+            if (emit) { o_im = im[(size_t)o_row * P.W + gx2]; o_gt = gt[(size_t)o_row * P.W + gx2]; }
+            __syncthreads();
+            // the adjoint row written ONE iteration ago by the first stage (made visible by this iteration's barrier)
+            const int pb = buf ^ 1;
+            v2f q01 = { 0.f, 0.f };
+            float q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const v2f wk = { w[k], w[k] };
+                q01 = __builtin_elementwise_fma(wk, *reinterpret_cast<const v2f *>(&s_d01[pb][tid + k]), q01);
+                q2 = fmaf(w[k], s_d2[pb][tid + k], q2);
+            }
+            constexpr int J2 = (J + 10) % 11;
+            hd01[J2] = q01; hd2[J2] = q2;
+            v2f r01 = { 0.f, 0.f };
+            float r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const int sl = (J2 + 1 + k) % 11;
+                const v2f wk = { w[k], w[k] };
+                r01 = __builtin_elementwise_fma(wk, hd01[sl], r01);
+                r2 = fmaf(w[k], hd2[sl], r2);
+            }
+            const float r0 = r01.x, r1 = r01.y;
+            if (emit) {
+                const float x = em * o_im + cc, y = o_gt;
+                const float d = x - y;
+                sum_l1 += fabsf(d);
+                const float gl1 = l1w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                const float gg = r0 + 2.f * x * r1 + y * r2 + gl1;
+                P.dL_dim[(size_t)vc * HW + (size_t)o_row * P.W + gx2] = em * gg;
+                sum_gm += gg * (em * o_im);
+                sum_gc += gg;
+            }
+        };
+        for (int base = i_first; base <= i_last; base += 11) {
+            if (base + 0 <= i_last) row(base + 0, IC<0>()); if (base + 1 <= i_last) row(base + 1, IC<1>());
+            if (base + 2 <= i_last) row(base + 2, IC<2>()); if (base + 3 <= i_last) row(base + 3, IC<3>());
+            if (base + 4 <= i_last) row(base + 4, IC<4>()); if (base + 5 <= i_last) row(base + 5, IC<5>());
+            if (base + 6 <= i_last) row(base + 6, IC<6>()); if (base + 7 <= i_last) row(base + 7, IC<7>());
+            if (base + 8 <= i_last) row(base + 8, IC<8>()); if (base + 9 <= i_last) row(base + 9, IC<9>());
+            if (base + 10 <= i_last) row(base + 10, IC<10>());
+        }
+    }
+    const float tl1 = block_sum(sum_l1, s_red), tss = block_sum(sum_s, s_red);
+    const float tgm = block_sum(sum_gm, s_red), tgc = block_sum(sum_gc, s_red);
+    if (threadIdx.x == 0) {
+        const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
+        P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
+        P.part_cam[2 * t] = tgm; P.part_cam[2 * t + 1] = tgc;
+    }
+}
+
 // one workgroup per view: fixed-order sums of the per-tile partials
 __global__ __launch_bounds__(kBlock) void k_photo_final(const PhP P)
 {
@@ -433,7 +622,18 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     for (int i = 0; i < 11; i++) P.win[i] = g[i] / sum;
     hipStream_t stream = (hipStream_t)hip_stream;
     const dim3 grid(P.tx, P.ty, n_views * 3);
-    if (ft == 64) hipLaunchKernelGGL(k_photo_fused<64>, grid, dim3(64), 0, stream, P);
+    // Two wave roles per strip (k_photo_split) for ONE view's worth of pixels - a launch that cannot fill the chip, where the
+    // second set of waves shortens every workgroup's row: 36.5 -> 29.7 us for a 512 x 375 view.  A batch of views keeps one
+    // thread per column for both stages: there the roles only add waves that wait for each other at the row barrier (the first
+    // stage is twice the second: 24 x 512^2 235 -> 258-330 us, 24 x 2048^2 -2 %).  T4D_PH_SPLIT=0/1 forces one or the other.
+    const char *split_env = getenv("T4D_PH_SPLIT");
+    const bool split = split_env ? atoi(split_env) != 0 : (long long)n_views * 3 * H * W < (1ll << 21);
+    if (split) {
+        if (ft == 64) hipLaunchKernelGGL(k_photo_split<64>, grid, dim3(128), 0, stream, P);
+        else if (ft == 128) hipLaunchKernelGGL(k_photo_split<128>, grid, dim3(256), 0, stream, P);
+        else if (ft == 192) hipLaunchKernelGGL(k_photo_split<192>, grid, dim3(384), 0, stream, P);
+        else hipLaunchKernelGGL(k_photo_split<256>, grid, dim3(512), 0, stream, P);
+    } else if (ft == 64) hipLaunchKernelGGL(k_photo_fused<64>, grid, dim3(64), 0, stream, P);
     else if (ft == 128) hipLaunchKernelGGL(k_photo_fused<128>, grid, dim3(128), 0, stream, P);
     else if (ft == 192) hipLaunchKernelGGL(k_photo_fused<192>, grid, dim3(192), 0, stream, P);
     else hipLaunchKernelGGL(k_photo_fused<256>, grid, dim3(256), 0, stream, P);
