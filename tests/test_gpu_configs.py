@@ -281,7 +281,9 @@ def _randomised_trial(trial, strict=False):
         if strict:
             check_grads(hg, g, v)
         else:
-            check_grads_modulo_flips(hg, g, v, flips, st["xy"][v], hip["radii"][v])
+            f64 = lambda: {k: t.numpy() for k, t in util.torch_oracle_render(cams[v], rv, dc[v], dd[v] if use_da else None,
+                                                                              da[v] if use_da else None)[1].items()}
+            check_grads_modulo_flips(hg, g, v, flips, st["xy"][v], hip["radii"][v], truth=f64)
         n_flips += len(flips)
     return n_flips
 
@@ -289,6 +291,15 @@ def _randomised_trial(trial, strict=False):
 @pytest.mark.parametrize("trial", range(12))
 def test_randomised_scenes_against_c_oracle(trial):
     _randomised_trial(trial)
+
+
+def test_soak_seed_2635_the_fp32_reference_is_the_noisy_one(render_build):
+    """Named regression (round 3's 2,000 further soak seeds on the final kernels): no flipped pixel, yet one Gaussian's dL/dscales
+    is 2.9e-4 of the tensor's largest entry (1.3e-7 absolute) away from the C oracle.  tools/diag_trial.py 2635: the C oracle is
+    8.2e-8 from the float64 autograd value, the kernels 6.9e-9 - a cancelling sum of a x8-scaled anisotropic splat rounded in
+    fp32 by the reference (by how much depends on the host: the C oracle is built -march=native).  The check accepts a Gaussian
+    that meets the tolerance against the float64 oracle."""
+    _randomised_trial(2635)
 
 
 def test_soak_seed_171_one_threshold_pixel(render_build):

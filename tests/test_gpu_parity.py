@@ -46,15 +46,20 @@ def flipped_pixels(hip, v, r, n_contrib_mine):
 FLIP_GRAD_REL = 5e-2
 
 
-def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_KEYS, rel=GRAD_REL):
+def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_KEYS, rel=GRAD_REL, truth=None):
     """check_grads where a handful of threshold decisions (`flips`, from flipped_pixels) differ from the oracle.  Every Gaussian
     is held to the plain tolerance (rel * max|reference| per tensor, and GRAD_ABS absolute) EXCEPT those with a flipped pixel in
     one of the 16x16 tiles of their 3-sigma rectangle - the pixels they are evaluated on: alpha >= 1/255 reaches 3.33 sigma at
     opacity 1, beyond the 3-sigma radius - where the flip moves that pixel's transmittance for every splat behind the flipped
     one and the "colour behind" for every splat in front of it.  Such a Gaussian's gradient differs by that pixel's whole
     contribution (soak seed 962: 1.4e-4 absolute, 0.25 % of the tensor's largest); it is held to FLIP_GRAD_REL of the tensor's
-    largest entry - a sanity bound, not a precision claim."""
+    largest entry - a sanity bound, not a precision claim.
+    `truth` (optional): a callable returning the float64 autograd oracle's gradients of this view.  The C oracle computes in
+    fp32 like the kernels and has rounding of its own (soak seed 2635: a cancelling scale gradient of a x8 anisotropic splat,
+    C oracle 8e-8 from the float64 value, HIP 7e-9); a Gaussian without a flipped pixel in reach that misses the tolerance
+    against the C oracle passes if it meets the SAME tolerance against the float64 oracle - evaluated only then."""
     tile = 16.0
+    truth_g = None
     ftx, fty = (flips[:, 1] // 16, flips[:, 0] // 16) if len(flips) else (np.zeros(0), np.zeros(0))
     for k in keys:
         if k not in ref_g or ref_g[k] is None or hip_g.get(k) is None:
@@ -68,6 +73,12 @@ def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_K
             x0, x1 = max(0, int((xy[i, 0] - r) / tile)), int((xy[i, 0] + r + tile - 1) / tile)      # tile_rect of t4d_raster.hip
             y0, y1 = max(0, int((xy[i, 1] - r) / tile)), int((xy[i, 1] + r + tile - 1) / tile)
             near = (ftx >= x0) & (ftx < x1) & (fty >= y0) & (fty < y1)
+            if not near.any() and truth is not None and err[i] < GRAD_ABS:
+                if truth_g is None:
+                    truth_g = truth()
+                t = np.asarray(truth_g[k], np.float64).reshape(a.shape)
+                if np.abs(a[i] - t[i]).max() <= rel * scale + 1e-9:
+                    continue                              # the fp32 reference is the one that is off here
             assert near.any(), f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} with no flipped pixel in reach"
             assert err[i] <= FLIP_GRAD_REL * scale, f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} is more than one pixel's share"
 
