@@ -407,7 +407,7 @@ def main():
     ap.add_argument("--cpu-sample-views", type=int, default=0)
     ap.add_argument("--frames-in-flight", dest="in_flight", type=int, default=int(os.environ.get("T4D_BENCH_IN_FLIGHT", "0")),
                     help="independent frames in flight on as many HIP streams (1 = one frame after the other on one stream; "
-                         "default: 2 for config 2, 1 for config 4, whose kernels fill the chip by themselves)")
+                         "default: 2)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 64 if args.scaling == "strong" else 50
@@ -446,7 +446,7 @@ def main():
     import topo4d_amd
 
     if args.in_flight < 1:
-        args.in_flight = 2 if args.config == "C2" else 1
+        args.in_flight = 2             # both configs (config 4 since the end of round 3: 4.20 -> 4.07 ms; `sequential` = one frame at a time)
     wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
     my_steps = strong_steps_per_rank if args.scaling == "strong" else args.steps
