@@ -407,7 +407,7 @@ def main():
     ap.add_argument("--cpu-sample-views", type=int, default=0)
     ap.add_argument("--frames-in-flight", dest="in_flight", type=int, default=int(os.environ.get("T4D_BENCH_IN_FLIGHT", "0")),
                     help="independent frames in flight on as many HIP streams (1 = one frame after the other on one stream; "
-                         "default: 2)")
+                         "default: 3 for config 2, 2 for config 4)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 64 if args.scaling == "strong" else 50
@@ -446,7 +446,9 @@ def main():
     import topo4d_amd
 
     if args.in_flight < 1:
-        args.in_flight = 2             # both configs (config 4 since the end of round 3: 4.20 -> 4.07 ms; `sequential` = one frame at a time)
+        # config 2: 0.430 / 0.425 / 0.433 ms with 2 / 3 / 4 frames in flight; config 4: 4.06 / 4.10 ms with 2 / 3 (one: 4.20) - end of
+        # round 3, same box; `sequential` in the JSON line is the same steps one frame at a time
+        args.in_flight = 3 if args.config == "C2" else 2
     wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
     my_steps = strong_steps_per_rank if args.scaling == "strong" else args.steps
