@@ -1674,8 +1674,12 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     // it with dL/dpixel afterwards; the recursion is linear, so the dot product is taken FIRST and a single scalar is
     // carried:  q_i = c_i . dL/dC (+ depth_i dL/dD + dL/dAlpha),  acc <- alpha_i q_i + (1 - alpha_i) acc  once splat i is done
     // (upstream applies the same update lazily, at the next contributor: same operands, same order, same bits).
-    float acc = 0.f;
-    const float tf_bg = T_final * (vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2);
+    // The BACKGROUND is the splat behind all others (colour bg, alpha 1): the recursion starts from its q = bg . dL/dC instead of
+    // from zero.  Upstream starts from zero and subtracts T_final / (1 - alpha_i) * (bg . dL/dC) from every dL/dalpha_i; with
+    // acc' = acc + T_final (bg . dL/dC) / T_i (T_i = transmittance in front of splat i) both the update acc' <- alpha q + (1 - alpha) acc'
+    // and dL/dalpha_i = (q_i - acc') T_i hold exactly - one multiply and one fused multiply-add less per step, and for a black
+    // background (Topo4D: helpers.py setup_camera, bg = 0) the same bits as before.
+    float acc = vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2;
 
     const uint32_t rmax_v = row_max_u32(last_contributor);
     uint32_t row_max[4];
@@ -1855,7 +1859,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         const float Tn = T * inv;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
-                        const float dL_dalpha = fmaf(q - acc, Tn, -tf_bg * inv);
+                        const float dL_dalpha = (q - acc) * Tn;
                         T = contrib ? Tn : T;
                         w = contrib ? alpha * Tn : 0.f;
                         e = contrib ? G * dL_dalpha : 0.f;
@@ -1872,7 +1876,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         w = alpha * T;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
-                        const float dL_dalpha = fmaf(q - acc, T, -tf_bg * inv);    // acc = the colour behind THIS splat
+                        const float dL_dalpha = (q - acc) * T;                     // acc = the colour behind THIS splat (background included)
                         e = G * dL_dalpha;
                         acc = fmaf(alpha, q, om * acc);                            // ... and now behind the next one towards the eye
                     }
@@ -1929,10 +1933,10 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         __syncthreads();
     }
     if (kp.tile_dot) {
-        // The suffix recursion has reached the eye: acc = sum_i T_i alpha_i q_i = <colour - T_final bg, dL/dC> (+ <depth, dL/dD> +
-        // <alpha, dL/dA>), so acc + tf_bg is this pixel's <outputs, cotangents> - the per-view sum costs one reduction per tile.
+        // The suffix recursion has reached the eye: acc = sum_i T_i alpha_i q_i + T_final bg . dL/dC = <colour, dL/dC> (+ <depth, dL/dD> +
+        // <alpha, dL/dA>), this pixel's <outputs, cotangents> - the per-view sum costs one reduction per tile.
         // One float per wave, no barrier: a workgroup's lifetime is what this launch is made of.
-        const float d = wave_sum_to_lane63(acc + tf_bg);
+        const float d = wave_sum_to_lane63(acc);
         if (lane == 63) kp.tile_dot[((size_t)v * kp.T + t_) * 4 + wave] = d;
     }
     T4D_STAMP(4);
