@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     // Suffix state of the replay.  Upstream keeps one running "colour behind me" per channel (+ depth, + alpha) and dots
     // it with dL/dpixel afterwards; the recursion is linear, so the dot product is taken FIRST and a single scalar is
     // carried:  q_i = c_i . dL/dC (+ depth_i dL/dD + dL/dAlpha),  acc <- alpha_i q_i + (1 - alpha_i) acc  once splat i is done
-    // (upstream applies the same update lazily, at the next contributor: same operands, same order, same bits).
+    // (upstream applies the same update lazily, at the next contributor).
     // The BACKGROUND is the splat behind all others (colour bg, alpha 1): the recursion starts from its q = bg . dL/dC instead of
     // from zero.  Upstream starts from zero and subtracts T_final / (1 - alpha_i) * (bg . dL/dC) from every dL/dalpha_i; with
     // acc' = acc + T_final (bg . dL/dC) / T_i (T_i = transmittance in front of splat i) both the update acc' <- alpha q + (1 - alpha) acc'
@@ -1859,11 +1859,12 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         const float Tn = T * inv;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
-                        const float dL_dalpha = (q - acc) * Tn;
+                        const float qma = q - acc;
+                        const float dL_dalpha = qma * Tn;
                         T = contrib ? Tn : T;
                         w = contrib ? alpha * Tn : 0.f;
                         e = contrib ? G * dL_dalpha : 0.f;
-                        acc = contrib ? fmaf(alpha, q, om * acc) : acc;
+                        acc = contrib ? fmaf(alpha, qma, acc) : acc;
                     } else if (contrib) {
 #endif
                         // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
@@ -1876,9 +1877,13 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         w = alpha * T;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
                         if (DA) q = fmaf(cd.w, ddep, q) + dalp;
-                        const float dL_dalpha = (q - acc) * T;                     // acc = the colour behind THIS splat (background included)
+                        const float qma = q - acc;                                 // acc = the colour behind THIS splat (background included)
+                        const float dL_dalpha = qma * T;
                         e = G * dL_dalpha;
-                        acc = fmaf(alpha, q, om * acc);                            // ... and now behind the next one towards the eye
+                        // ... and now behind the next one towards the eye: alpha q + (1 - alpha) acc as acc + alpha (q - acc), the
+                        // difference being at hand (one instruction instead of two; upstream's two-product form rounds differently
+                        // in the last bit)
+                        acc = fmaf(alpha, qma, acc);
                     }
                     // lanes that do not contribute carry e = w = 0, so their ten products are exact zeros
                     const v2f ed = e * d, edd = ed * d, wdp = w * dp01;
