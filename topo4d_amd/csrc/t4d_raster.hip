@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     const float bg1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(vr[36])));
     const float bg2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(vr[37])));
     unsigned long long done_m = __ballot(!inside);   // pixels that take no more splats, as a wave mask
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f, D = 0.f;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
     for (uint32_t b = 0; b < n; b += kFB) {
@@ -1419,7 +1419,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 const float w = ok ? alpha[u] * T : 0.f;
                 C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
                 D = fmaf(cd.w, w, D);
-                Wt += w;
                 T = ok ? test_T : T;
                 last_e = ok ? e[u] : last_e;
                 T4D_COUNT_ADD(12, __builtin_popcountll(live & ~below));
@@ -1440,7 +1439,9 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         oc[HW + pix] = C1 + T * bg1;
         oc[2 * HW + pix] = C2 + T * bg2;
         kp.out_depth[(size_t)v * HW + pix] = D;
-        kp.out_alpha[(size_t)v * HW + pix] = Wt;
+        // alpha = sum of the blend weights w_i = T_i - T_(i+1): the sum telescopes to 1 - T_final, which is at hand (upstream adds
+        // the weights up one by one; one add per step less here, and one rounding instead of one per splat)
+        kp.out_alpha[(size_t)v * HW + pix] = 1.f - T;
     }
     __syncthreads();                                 // staging buffers are reused by the next tile
     }
