@@ -331,8 +331,8 @@ def drop_in_probe(dev):
         rv = boundary.params2rendervar(params)
         (rv["means3D"].sum() + rv["rotations"].sum() + rv["opacities"].sum() + rv["scales"].sum() + rv["colors_precomp"].sum()).backward()
 
-    saved = (rasterizer._SYNC_MODE, rasterizer._SYNC_MODE_EXPLICIT)
-    rasterizer._SYNC_MODE_EXPLICIT = False                 # what an unmodified train.py gets: the drop-in's default mode
+    saved = rasterizer._save_sync_mode()
+    rasterizer._restore_sync_mode(("checked", False))      # what an unmodified train.py gets: the drop-in's default mode
     out = {"workload": "1 camera per iteration, P=8280, 512x375, params2rendervar -> GaussianRasterizer -> backward (train.py:661-673)",
            "sync_mode": "auto (drop-in default)"}
     try:
@@ -347,7 +347,7 @@ def drop_in_probe(dev):
             torch.cuda.synchronize(dev)
             out[name] = round(n / (time.perf_counter() - t0), 1)
     finally:
-        rasterizer._SYNC_MODE, rasterizer._SYNC_MODE_EXPLICIT = saved
+        rasterizer._restore_sync_mode(saved)
     out["note"] = ("host-bound: an iteration is the reference's own torch ops (params2rendervar forward + autograd backward, "
                    "params2rendervar_only_it_per_s) plus the drop-in call (it_per_s_without_params2rendervar); GPU time per view is single_view.gpu_us_per_view")
     return out

@@ -72,7 +72,8 @@ def test_rccl_branch_with_a_process_group_of_one_rank():
     asynchronous all_gather_into_tensor of the per-view losses on the step's stream, barrier(device_ids=...), the MAX
     all_reduce of the timing and destroy_process_group all execute once on the test box's GPU.  The gathered losses equal the
     single-process ones bit for bit, and the line carries both scaling modes."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_DIST_BACKEND="nccl", T4D_BENCH_DUMP_LOSSES="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_DIST_BACKEND="nccl", T4D_BENCH_DUMP_LOSSES="2",
+               T4D_FORCE_COLLECTIVES="1")       # a one-rank group takes the no-collective fast path otherwise (dist._group_active)
     common = ["--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras"]
     one = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "3"] + common, env)

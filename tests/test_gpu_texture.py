@@ -100,6 +100,7 @@ def _sharded_bake_worker(rank, world, port, out_path, backend="gloo"):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":                                                 # RCCL: one rank per GPU, so world == 1 on the test box
+        os.environ["T4D_FORCE_COLLECTIVES"] = "1"                         # (a one-rank group skips the collective otherwise)
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:

@@ -119,3 +119,39 @@ def test_graphed_views_argument_checks_need_no_gpu():
         loop.GraphedViews(p, [], FusedAdamPins(groups, capturable=True))
     opt = FusedAdamPins(groups, capturable=True)
     assert opt.steps() == [0]
+
+
+def test_rasterizer_keeps_the_nn_module_contract_although_it_builds_its_state_lazily():
+    """.eval() on a fresh instance used to be undone by the lazy nn.Module set-up, and assigning a submodule raised."""
+    cam = scene.camera_rig(32, 32, n_views=1)[0]
+    r = topo4d_amd.GaussianRasterizer(cam)
+    assert r.eval().training is False and r.train().training is True
+    r = topo4d_amd.GaussianRasterizer(cam)
+    r.train(False)
+    assert r.training is False
+    r = topo4d_amd.GaussianRasterizer(raster_settings=cam)
+    r.head = torch.nn.Linear(2, 2)
+    assert "head" in dict(r.named_modules()) and len(list(r.parameters())) == 2
+    assert r.raster_settings is cam
+    seen = []
+    h = torch.nn.modules.module.register_module_forward_pre_hook(lambda m, a: seen.append(type(m).__name__))
+    try:
+        with pytest.raises(Exception):                        # CPU tensors: the call itself fails, but the global hook ran first
+            r(torch.zeros(1, 3), None, torch.zeros(1, 1), colors_precomp=torch.zeros(1, 3), scales=torch.zeros(1, 3), rotations=torch.zeros(1, 4))
+    finally:
+        h.remove()
+    assert seen == ["GaussianRasterizer"]
+
+
+def test_sync_mode_save_restore_leaves_no_trace():
+    saved = rasterizer._save_sync_mode()
+    try:
+        rasterizer._restore_sync_mode(("checked", False))
+        assert topo4d_amd.get_sync_mode() == "checked" and topo4d_amd.get_sync_mode(drop_in=True) == "auto"
+        inner = rasterizer._save_sync_mode()
+        topo4d_amd.set_sync_mode("lazy")
+        assert topo4d_amd.get_sync_mode(drop_in=True) == "lazy"
+        rasterizer._restore_sync_mode(inner)
+        assert topo4d_amd.get_sync_mode(drop_in=True) == "auto"      # the drop-in's default is the default again
+    finally:
+        rasterizer._restore_sync_mode(saved)

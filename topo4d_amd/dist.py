@@ -5,14 +5,24 @@ The reference is single-process / single-GPU; this is the one 
 every (frame, view) render reads the same replicated Gaussians and its own camera, so units are independent
 (SURVEY.md §8e).  Rank r of W takes units {u : u mod W == r}.  No data-path collective exists; the only exchange
 is an all_gather of the per-view scalar photometric losses (a few floats per rank) — RCCL on GPU ("nccl" backend
-is RCCL on ROCm), gloo in the CPU tests.  The collectives run whenever a process group is initialised, also one of a
-single rank: that is how the RCCL calls are exercised on a one-GPU test box (tests/test_gpu_multirank.py).
+is RCCL on ROCm), gloo in the CPU tests.  A process group of ONE rank takes the no-collective fast path like no process
+group at all, unless T4D_FORCE_COLLECTIVES=1 is set: that is how the RCCL calls are exercised on a one-GPU test box
+(tests/test_gpu_multirank.py).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import torch
+
+
+def _group_active() -> bool:
+    """True when a collective has to run: a process group exists and has more than one rank (or T4D_FORCE_COLLECTIVES=1)."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("T4D_FORCE_COLLECTIVES") == "1"
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -30,7 +40,7 @@ def gather_losses(local: torch.Tensor, n_units: int = None) -> torch.Tensor:
     """all_gather of per-unit scalar losses.  `local` is this rank's 1-D tensor (round-robin shard of n_units
     units; ranks may hold different counts).  Returns the losses of ALL units in unit order, on every rank."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized():
+    if not _group_active():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     if local.is_cuda and dist.get_backend() != "nccl":        # gloo dry runs: stage through the host
@@ -59,7 +69,7 @@ def gather_losses_async(local: torch.Tensor, out: torch.Tensor):
     world*local.numel() elements in rank-major order (out.view(world,-1).t() is unit order) and, like `local`, must not be
     rewritten before `work.wait()`."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized():
+    if not _group_active():
         out[: local.numel()].copy_(local)
         return out, None
     if local.is_cuda and dist.get_backend() != "nccl":        # gloo dry runs: synchronous, through the host
@@ -75,7 +85,7 @@ def all_reduce_grads(grads: Sequence[torch.Tensor]) -> None:
     """Optional data-parallel training step: sum the (already view-summed) parameter gradients over ranks.
     Changes the optimisation schedule versus train.py:661-673 (one Adam step per view) — see DESIGN.md."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized():
+    if not _group_active():
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -99,7 +109,7 @@ def gather_bands(band: torch.Tensor, n_rows: int) -> torch.Tensor:
     """all_gather of per-rank row bands ([rows_r, ...], band_bounds order) into the full [n_rows, ...] tensor on every rank.
     Bands may differ by one row; they are padded to the tallest for the collective."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized():
+    if not _group_active():
         return band
     world = dist.get_world_size()
     if band.is_cuda and dist.get_backend() != "nccl":         # gloo dry runs: stage through the host

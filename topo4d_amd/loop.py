@@ -106,7 +106,7 @@ class GraphedViews:
         leaves = [g["params"][0] for g in optimizer.param_groups]
         # the warm-up below takes real optimisation steps; everything it touches is restored before the captures
         snap_p = [p.detach().clone() for p in leaves]
-        prev_mode = R.get_sync_mode()
+        prev_mode = R._save_sync_mode()              # restored without a trace (the drop-in's default must stay the default)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -145,7 +145,7 @@ class GraphedViews:
                 self._capture_all(R, fused_loss, extra_loss)
         finally:
             R._BATCH_LOG = None
-            R.set_sync_mode(prev_mode)
+            R._restore_sync_mode(prev_mode)
         optimizer.zero_grad(set_to_none=True)
 
     def _capture_all(self, R, fused_loss, extra_loss) -> None:

@@ -59,6 +59,19 @@ _BATCH_LOG = None       # when a list: every ViewBatch that runs a forward is ap
                         # of its captures to read their overflow flags back later)
 
 
+class _Pending:
+    """One un-synchronised forward of the "auto" mode whose 16-byte binning status is still on its way to pinned host memory."""
+    __slots__ = ("track", "slot", "cap", "done", "overflow", "need")
+
+    def __init__(self, track, slot, cap):
+        self.track, self.slot, self.cap = track, slot, cap
+        self.done, self.overflow, self.need = False, False, 0
+
+    def landed(self) -> bool:
+        h = self.track.host
+        return int(h[self.slot, 0]) != -1 and int(h[self.slot, 1]) != -1      # (both halves: a copy caught half-way reads as "not yet")
+
+
 class _AutoTrack:
     """Bookkeeping of the "auto" sync mode for one (scene size, camera set): a ring of 16-byte status blocks in pinned host
     memory, one per un-synchronised forward still in flight, and the largest need seen.  A slot is filled with an impossible
@@ -77,72 +90,120 @@ class _AutoTrack:
         self.count = 0                                  # slots in flight
         self.need = 0
 
-    def claim(self, cap: int):
-        """Reserves the next slot for a forward that is about to be enqueued; returns the status pointer to pass to it."""
+    def claim(self, cap: int) -> "_Pending":
+        """Reserves the next slot for a forward that is about to be enqueued; `self.args[entry.slot]` is the status pointer to
+        pass to it."""
         if self.count == self.RING:                     # the host is RING forwards of this camera set ahead of the GPU
             poll_truncation()
             if self.count == self.RING:
                 torch.cuda.synchronize()
-                poll_truncation()
-                if self.count == self.RING:             # statuses that can never land (their forward failed): forget them
-                    for e in [e for e in _PENDING if e[0] is self]:
-                        _PENDING.remove(e)
-                    self.count = 0
+                # everything that was enqueued has landed by now: harvest it (a truncated pass among them raises here); a slot
+                # that still reads "not yet" belongs to a forward that was never enqueued and can only be forgotten
+                poll_truncation(_after_sync=True)
         i = self.head
         self.host[i, 0] = -1
         self.host[i, 1] = -1
         self.head = (i + 1) % self.RING
         self.count += 1
-        _PENDING.append((self, i, cap))
-        return self.args[i]
+        entry = _Pending(self, i, cap)
+        _PENDING.append(entry)
+        return entry
+
+    def unclaim(self, entry: "_Pending") -> None:
+        """The forward this slot was claimed for failed before its status copy was enqueued: give the slot back."""
+        if not entry.done:
+            entry.done = True
+            try:
+                _PENDING.remove(entry)
+            except ValueError:
+                pass
+            self.count -= 1
+            if (entry.slot + 1) % self.RING == self.head:
+                self.head = entry.slot
 
 
-_PENDING = deque()      # (track, slot, capacity used) of the un-synchronised forwards, in submission order
+_PENDING = deque()      # _Pending entries of the un-synchronised forwards, in submission order
 
 
-def poll_truncation() -> None:
+def _harvest(entry: "_Pending"):
+    """Takes a landed status out of the books; returns (need, capacity used) if that forward was truncated."""
+    track = entry.track
+    raw0 = int(track.host[entry.slot, 0])
+    entry.done = True
+    track.count -= 1
+    entry.overflow, entry.need = bool(raw0 & 0xffffffff), (raw0 >> 32) & 0xffffffff
+    track.need = max(track.need, entry.need)
+    if entry.overflow:
+        if track.key is not None:
+            _CAPACITY[track.key] = max(_CAPACITY.get(track.key, 0), _round_capacity(track.need))
+        return (entry.need, entry.cap)
+    return None
+
+
+def _truncation_error(truncated) -> RuntimeError:
+    return RuntimeError(
+        f"topo4d_amd (sync_mode='auto'): a render needed {truncated[0]} (Gaussian,tile) pairs per view but its arena held "
+        f"{truncated[1]}; it was truncated (incomplete tile lists; its backward returns no gradients). The arena has been "
+        "enlarged: re-run that iteration, or use set_sync_mode('checked') for scenes that change abruptly.")
+
+
+def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = False) -> None:
     """"auto" sync mode: look at every binning status that has landed since the last look - of ALL camera sets, not only
-    the one being rendered - grow the arenas they ask for, and raise RuntimeError if any of those forwards was truncated
-    (its backward returned zero gradients, see t4d_rasterize_backward).  Every auto-mode forward calls this first; an
-    optimisation loop may also call it right before `optimizer.step()` to learn about a truncated pass as early as the GPU
-    allows.  Never synchronises: statuses are inspected in submission order, the first one still in flight ends the look."""
+    the one being rendered - grow the arenas they ask for, and raise RuntimeError if any of those forwards was truncated.
+    Every auto-mode forward calls this first, and every auto-mode BACKWARD calls it for its own forward (`wait_for`, below) before
+    it returns a gradient, so a truncated pass raises inside `loss.backward()` - before `optimizer.step()`.
+    Without `wait_for` it never synchronises: statuses are inspected in submission order, the first one still in flight ends
+    the look.  With `wait_for` (the entry of one forward) it returns only once THAT status has landed: the copy was enqueued
+    behind the forward's binning kernels, long before the loss and the backward were, so it has normally arrived already;
+    if not, the host spins on the two pinned words (and falls back to a stream synchronisation after a second)."""
     truncated = None
+    if wait_for is not None and not wait_for.done and not wait_for.landed():
+        import time
+        t0 = time.perf_counter()
+        while not wait_for.landed():
+            if time.perf_counter() - t0 > 1.0:
+                torch.cuda.synchronize()
+                break
     while _PENDING:
-        track, i, cap_used = _PENDING[0]
-        raw0, raw1 = int(track.host[i, 0]), int(track.host[i, 1])
-        if raw0 == -1 or raw1 == -1:                    # (both halves: a copy caught half-way reads as "not yet")
+        entry = _PENDING[0]
+        if not entry.landed():
+            if _after_sync:                             # can never land: its forward was not enqueued
+                _PENDING.popleft()
+                entry.done = True
+                entry.track.count -= 1
+                continue
             break
         _PENDING.popleft()
-        track.count -= 1
-        overflow, need = raw0 & 0xffffffff, (raw0 >> 32) & 0xffffffff
-        track.need = max(track.need, need)
-        if overflow:
-            truncated = (need, cap_used)
-            if track.key is not None:
-                _CAPACITY[track.key] = max(_CAPACITY.get(track.key, 0), _round_capacity(track.need))
+        truncated = _harvest(entry) or truncated
+    if wait_for is not None and not wait_for.done and wait_for.landed():
+        # an earlier status of ANOTHER stream is still in flight: take this one out of order
+        try:
+            _PENDING.remove(wait_for)
+        except ValueError:
+            pass
+        truncated = _harvest(wait_for) or truncated
     if truncated is not None:
-        raise RuntimeError(
-            f"topo4d_amd (sync_mode='auto'): an earlier render needed {truncated[0]} (Gaussian,tile) pairs per view but its "
-            f"arena held {truncated[1]}; it was truncated and its backward returned zero gradients. The arena has been "
-            "enlarged; re-run that iteration, or use set_sync_mode('checked') for scenes that change abruptly.")
+        raise _truncation_error(truncated)
 
 
 def set_sync_mode(mode: str) -> None:
     """Without a call of this function `ViewBatch` / `rasterize_views` run "checked" and the one-view drop-in
     `GaussianRasterizer` - Topo4D's optimisation loop, one camera per call thousands of times per frame (train.py:661-673) -
-    runs "auto" (a `debug=True` camera is always checked).  After a call everything runs the mode it names.
+    runs "auto" for calls that will be differentiated and "checked" otherwise (no_grad renders, `debug=True` cameras).
+    After a call everything runs the mode it names.
     "checked": the forward synchronises once, after the binning sizes are known, and re-runs
     with a larger pair arena if it was too small — exactly where upstream reads `num_rendered` back.
     "lazy": never synchronises; tile lists are truncated (memory-safe) if the arena learned by earlier checked
     calls is too small, and `ViewBatch.fetch_status()` / `last_status()` reports it.  Use lazy only when the
     capacity was established by a checked call on (nearly) the same scene — bench.py does.
     "auto": for optimisation loops.  The first forward of every (scene size, camera set) is checked; afterwards the
-    forward does not synchronise, the binning status is copied to pinned host memory asynchronously and inspected at the
-    next auto-mode forward of ANY camera set (`poll_truncation`; at most 8 calls of one camera set later if the host runs
-    ahead of the GPU): the arena is grown as soon as 75 % of it is in use (it is sized 1.5x the largest need seen), so
-    consecutive iterations of an optimiser cannot overflow it; should a previous call nevertheless have been truncated
-    (the scene jumped by more than a third between two calls), its backward returned zero gradients and a RuntimeError
-    says so at the next forward (or at an explicit `poll_truncation()` before `optimizer.step()`)."""
+    forward does not synchronise: the binning status is copied to pinned host memory asynchronously, right behind the binning
+    kernels.  The arena is grown as soon as 75 % of it is in use (it is sized 1.5x the largest need seen), so consecutive
+    iterations of an optimiser cannot overflow it.  Should a forward nevertheless be truncated (the scene jumped by more than
+    a third between two calls), ITS OWN BACKWARD raises RuntimeError before it returns any gradient - `loss.backward()` fails,
+    `optimizer.step()` is never reached with the gradients of an incomplete render - and the arena has been enlarged for the
+    re-run.  (The backward looks at the pinned status words; they have normally landed long before, otherwise it waits for
+    them - not for the stream.)  `poll_truncation()` does the same look on demand."""
     global _SYNC_MODE, _SYNC_MODE_EXPLICIT
     if mode not in ("checked", "lazy", "auto"):
         raise ValueError("sync mode must be 'checked', 'lazy' or 'auto'")
@@ -150,8 +211,23 @@ def set_sync_mode(mode: str) -> None:
     _SYNC_MODE_EXPLICIT = True
 
 
-def get_sync_mode() -> str:
+def get_sync_mode(drop_in: bool = False) -> str:
+    """The mode `ViewBatch` / `rasterize_views` run (drop_in=False) or the one a differentiated call of the one-view
+    `GaussianRasterizer` runs (drop_in=True: "auto" until set_sync_mode() names another)."""
+    if drop_in and not _SYNC_MODE_EXPLICIT:
+        return "auto"
     return _SYNC_MODE
+
+
+def _save_sync_mode():
+    """(mode, was it set explicitly) - for code that switches modes temporarily and must leave NO trace (loop.GraphedViews,
+    bench.py): `set_sync_mode(get_sync_mode())` would turn the drop-in's default into an explicit choice for good."""
+    return (_SYNC_MODE, _SYNC_MODE_EXPLICIT)
+
+
+def _restore_sync_mode(saved) -> None:
+    global _SYNC_MODE, _SYNC_MODE_EXPLICIT
+    _SYNC_MODE, _SYNC_MODE_EXPLICIT = saved
 
 
 def _initial_capacity(P: int) -> int:
@@ -294,6 +370,7 @@ class ViewBatch:
         self.inputs = None
         self.radii = None
         self.plan = None
+        self.pending = None
         self.flat_grads = False                         # True (autograd path, V = 1): gradients come back without the view axis
 
     # -- helpers ---------------------------------------------------------------------------------------------
@@ -388,12 +465,14 @@ class ViewBatch:
         status = plan.status
         lib = self.lib
         stream = _raw_stream(dev)
+        pending = None
         for _attempt in range(6):
             flags = self._flags(P, checked)
             status_arg = plan.status_ref
             if track is not None and not checked:
                 flags |= _lib.T4D_FLAG_ASYNC_STATUS
-                status_arg = track.claim(cap)
+                pending = track.claim(cap)
+                status_arg = track.args[pending.slot]
             prob = T4DProblem(T4D_ABI_VERSION, V, P, H, W, self.sh_degree, M, self.scale_modifier, cap, flags, 0)
             nbytes = plan.state_bytes.get(cap)
             if nbytes is None:
@@ -408,6 +487,9 @@ class ViewBatch:
             rc = lib.t4d_rasterize_forward(C.byref(prob), plan.fio_ref, status_arg, stream)
             if rc == T4D_OK:
                 break
+            if pending is not None:                      # the status of a failed forward never lands: give its slot back
+                track.unclaim(pending)
+                pending = None
             if rc == T4D_ERR_PAIR_OVERFLOW:
                 cap = _round_capacity(status.max_pairs_per_view)
                 continue
@@ -426,6 +508,7 @@ class ViewBatch:
         else:
             self.last_status = None
         self.prob, self.state, self.radii = prob, state, radii
+        self.pending = pending                           # "auto" mode: this forward's status, looked at by its backward
         if _BATCH_LOG is not None:
             _BATCH_LOG.append(self)
         self.inputs = (means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs)
@@ -441,6 +524,14 @@ class ViewBatch:
         if self.inputs is None:
             raise RuntimeError("this ViewBatch's inputs are owned by an autograd graph (GaussianRasterizer / rasterize_views): "
                                "call .backward() on the loss instead of ViewBatch.backward()")
+        pending = self.pending
+        if pending is not None:
+            # "auto" mode: no gradient of a truncated render ever leaves this function (the status was copied out right behind
+            # the forward's binning kernels: normally two host loads, see poll_truncation)
+            if not pending.done:
+                poll_truncation(wait_for=pending)
+            if pending.overflow:
+                raise _truncation_error((pending.need, pending.cap))
         dev = self.device
         means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs = self.inputs
         V, P, H, W = self.V, int(means3D.shape[0]), self.H, self.W
@@ -616,6 +707,13 @@ def _spec_of(s: GaussianRasterizationSettings, device) -> _CallSpec:
     return spec
 
 
+try:
+    from torch.nn.modules.module import _has_any_global_hook as _has_global_hooks
+except ImportError:                                          # pragma: no cover - torch without the helper: take the slow path
+    def _has_global_hooks() -> bool:
+        return True
+
+
 class GaussianRasterizer(nn.Module):
     """Drop-in for `diff_gaussian_rasterization.GaussianRasterizer` (constructed per call at train.py:307).
 
@@ -626,14 +724,27 @@ class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         object.__setattr__(self, "raster_settings", raster_settings)
 
-    def __getattr__(self, name):
+    def _module_state(self) -> None:
         if "_modules" not in self.__dict__:                 # first use of the nn.Module state
+            nn.Module.__init__(self)
+
+    def __getattr__(self, name):
+        if "_modules" not in self.__dict__:
             nn.Module.__init__(self)
             return getattr(self, name)
         return nn.Module.__getattr__(self, name)
 
+    def __setattr__(self, name, value):                     # (assigning a submodule / parameter / flag to a fresh instance)
+        self._module_state()
+        nn.Module.__setattr__(self, name, value)
+
+    def train(self, mode: bool = True):                     # .eval() on a fresh instance must not be undone by the lazy set-up
+        self._module_state()
+        return nn.Module.train(self, mode)
+
     def __call__(self, *args, **kwargs):
-        if "_forward_hooks" in self.__dict__ and (self._forward_hooks or self._forward_pre_hooks):
+        if ("_forward_hooks" in self.__dict__ and (self._forward_hooks or self._forward_pre_hooks)) or _has_global_hooks():
+            self._module_state()
             return nn.Module.__call__(self, *args, **kwargs)
         return self.forward(*args, **kwargs)
 
@@ -662,9 +773,17 @@ class GaussianRasterizer(nn.Module):
         if not means3D.is_cuda:
             raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
         spec = _spec_of(self.raster_settings, means3D.device)
-        if not _SYNC_MODE_EXPLICIT and spec.sync_mode is None:
-            spec.sync_mode = "auto"          # the optimisation-loop default of the one-view drop-in (see set_sync_mode)
-        elif _SYNC_MODE_EXPLICIT and spec.sync_mode is not None:
-            spec.sync_mode = None
+        if _SYNC_MODE_EXPLICIT:
+            spec.sync_mode = None            # whatever set_sync_mode() named
+        elif torch.is_grad_enabled() and (means3D.requires_grad or (colors_precomp is not None and colors_precomp.requires_grad)
+                                          or opacities.requires_grad or (scales is not None and scales.requires_grad)
+                                          or (rotations is not None and rotations.requires_grad)
+                                          or (shs is not None and shs.requires_grad)
+                                          or (cov3D_precomp is not None and cov3D_precomp.requires_grad)):
+            # the optimisation-loop default of the one-view drop-in: un-synchronised, and the call's own backward refuses to
+            # return gradients of a truncated render (see set_sync_mode)
+            spec.sync_mode = "auto"
+        else:
+            spec.sync_mode = "checked"       # nothing will be differentiated (evaluation renders): upstream's own behaviour
         # (color[3,H,W], radii[P], depth[1,H,W], alpha[1,H,W]) - the four tensors train.py:307 unpacks
         return _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, spec)
