@@ -3,7 +3,7 @@
 bench.py — rasterizer forward+backward views/sec on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4] [--opacity A|B] [--scaling weak|strong]
-                    [--frames-in-flight F] [--no-cpu-baseline] [--no-extras]
+                    [--shard frames|views] [--allreduce-grads] [--frames-in-flight F] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -19,13 +19,21 @@ with F = 1 (a kernel alone on the chip).
 Multi-GPU (BASELINE config 3): the 64-frame sequence is sharded by frame — rank r renders frames r, r+N, ...
   --scaling weak   (default; what the driver runs): every rank times K steps, per-GPU work is fixed (24 views per step);
   --scaling strong : the job is fixed — K frame-steps in total (default 64 = config 3's sequence), K/N per rank.
+  --shard views    : the split Topo4D's REAL loop could use (frames are sequential there, train.py:646: frame t starts from
+                     frame t-1): every rank steps through ALL frames and renders views r::N of each (24/8 = 3 views per rank);
+                     --allreduce-grads adds the data-parallel gradient all_reduce.  The default command carries this figure too
+                     (`view_sharded`), next to the frame-sharded `value` / `strong`.
 The only collective is an RCCL all_gather of the per-view scalar losses (24 floats per rank per step), overlapped with the
 next step.
 
 The JSON line carries `roofline` (dominant kernel by HIP-event time, algorithmic bytes per launch, HBM traffic and the
 vector-ALU counters of the committed rocprofv3 passes), `cpu_baseline` (oracle/raster_oracle.c, OpenMP, bounded sample,
-min of 5), `scenario_b` (the same workload with unsaturated opacities), `single_view` (the reference's own call shape:
-one camera per call, P = 8,280, 512x375) and `sequential` — see DESIGN.md §Measurement.
+min of 5), `repeats` (every figure is the median of >= 5 timed regions of >= 100 ms each: a region is the --steps block
+repeated as often as that takes), `scenario_b` (unsaturated opacities), `single_view` (the reference's own call shape: one
+camera per call, P = 8,280, 512x375), `small_v` (1 and 3 views of the config-2 scene per call: a view-sharded rank's launch),
+`forecast` (step time at 24 / 12 / 6 / 3 views => view-sharded strong scaling at 2 / 4 / 8 GPUs), `view_sharded` (the same
+split executed: rank r renders views r::N of every frame), `c4` (BASELINE config 4 with its own roofline), `dense_1m` (one view,
+P = 10^6, 4096x3008), `full_iteration` (render + fused loss + Adam/pins), `drop_in` and `sequential` — see DESIGN.md §Measurement.
 """
 from __future__ import annotations
 
@@ -140,7 +148,8 @@ class Workload:
     same reason): `in_flight` of them are in flight on as many HIP streams, each with its own state buffers, so that the
     latency-bound binning kernels of one frame run beside the issue-bound render kernels of the other."""
 
-    def __init__(self, cfgname, opacity, dev, rank=0, world=1, in_flight=2, n_frames=64, resident=8, gather=None):
+    def __init__(self, cfgname, opacity, dev, rank=0, world=1, in_flight=2, n_frames=64, resident=8, gather=None,
+                 view_shard=None, allreduce_grads=False, n_views=None):
         from scaffold import reference_boundary as boundary, scene
         from topo4d_amd import ViewBatch, dist as t4d_dist, pack_views
         self.t4d_dist = t4d_dist
@@ -156,12 +165,26 @@ class Workload:
         cams = scene.camera_rig(H, W, n_views=V, device=dev, true_campos=cfg["sh_degree"] is not None)
         if cfg["sh_degree"] is not None:
             cams = [c._replace(sh_degree=cfg["sh_degree"]) for c in cams]
-        views = pack_views(cams, dev)
         dc, _, _ = scene.output_cotangents(V, H, W, seed=0)
+        # view_shard = (r, N): this workload renders views r::N of EVERY frame (the split of SURVEY 8e / BASELINE config 3);
+        # n_views = k: the first k::(24/k)-strided views (the launch of one rank of a 24/k-way view shard, for `forecast`)
+        self.allreduce_grads = allreduce_grads
+        self.full_views = V
+        if view_shard is not None:
+            mine = t4d_dist.shard_units(V, view_shard[0], view_shard[1])
+        elif n_views is not None and n_views < V:
+            mine = list(range(0, V, V // n_views))[:n_views]
+        else:
+            mine = list(range(V))
+        self.my_views = mine
+        cams = [cams[i] for i in mine]
+        dc = dc[mine]
+        self.V = V = len(mine)
+        views = pack_views(cams, dev)
         self.dc = dc.to(dev).contiguous()
         # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
         self.n_frames = n_frames
-        my_frames = t4d_dist.shard_units(n_frames, rank, world)
+        my_frames = t4d_dist.shard_units(n_frames, rank, world) if view_shard is None else list(range(n_frames))
         self.rv_frames = []
         for t in my_frames[: max(1, min(len(my_frames), resident))]:
             p = dict(params)
@@ -200,6 +223,11 @@ class Workload:
             # per-view scalar loss term <colour, dL/dcolour>: the backward's replay ends holding exactly this inner product per
             # pixel, so it comes out of t4d_rasterize_backward (cotangent_dot), not out of a second pass over both images
             g = b.backward(self.dc, cotangent_dot=losses)
+            if self.allreduce_grads:
+                # data-parallel training step over a view shard: the view-summed parameter gradients are summed over the ranks
+                # (~14 floats x P; changes train.py:661-673's one-Adam-step-per-view schedule, so it is optional)
+                summed = [t.sum(0) for t in g.values() if t is not None]
+                self.t4d_dist.all_reduce_grads(summed)
             if self.gather:
                 out, work = self.t4d_dist.gather_losses_async(losses, self.gath_bufs[k])
                 self.pending[k] = work
@@ -226,8 +254,14 @@ class Workload:
         return [b.fetch_status() for b in self.batches]
 
 
-def timed_run(wl, steps, warmup, prewarm_s, barrier, all_reduce_max):
-    """W untimed steps (after a clock-settling pre-warm), then EXACTLY `steps` steps between two barriers."""
+MIN_REGION_S = 0.1      # a timed region lasts at least this long: the --steps block is repeated as often as that takes
+N_REGIONS = 5           # ... and there are this many regions; figures are the median, min and max ride along
+
+
+def timed_run(wl, steps, warmup, prewarm_s, barrier, all_reduce_max, regions=N_REGIONS, min_region_s=MIN_REGION_S):
+    """W untimed steps (after a clock-settling pre-warm), then `regions` timed regions, each EXACTLY `blocks * steps` steps
+    between two barriers (barrier + torch.cuda.synchronize on both sides, MAX over ranks).  Returns (median seconds per
+    block of `steps` steps, host enqueue seconds per block, stats dict)."""
     dev = wl.dev
     # A GPU that has just been idle (fresh box, or a profiler run before this one) needs tens of milliseconds of work
     # before its clocks settle: a cold 50-step run measured 1.23 ms/step against 0.62 warm.  Untimed, like the W steps.
@@ -241,16 +275,29 @@ def timed_run(wl, steps, warmup, prewarm_s, barrier, all_reduce_max):
     for i in range(n_pre):
         wl.step(i)
     torch.cuda.synchronize(dev)
+    blocks = max(1, int(-(-min_region_s // max(est * steps, 1e-6)))) if min_region_s > 0 else 1
+    blocks = int(all_reduce_max(float(min(blocks, 100000))))
     for i in range(warmup):
         wl.step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        wl.step(i)
-    t_enqueue = time.perf_counter() - t0       # host time to enqueue the steps (GPU still running)
-    barrier()
-    dt = time.perf_counter() - t0
-    return all_reduce_max(dt), t_enqueue
+    times, enq = [], []
+    for _ in range(max(1, regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for _b in range(blocks):
+            for i in range(steps):
+                wl.step(i)
+        t_enqueue = time.perf_counter() - t0       # host time to enqueue the steps (GPU still running)
+        barrier()
+        dt = time.perf_counter() - t0
+        times.append(all_reduce_max(dt) / blocks)
+        enq.append(t_enqueue / blocks)
+    srt = sorted(times)
+    med = srt[len(srt) // 2]
+    stats = {"regions": len(times), "blocks_per_region": blocks, "steps_per_region": blocks * steps,
+             "region_ms": round(1e3 * med * blocks, 3),
+             "ms_per_step": {"min": round(1e3 * srt[0] / steps, 4), "median": round(1e3 * med / steps, 4), "max": round(1e3 * srt[-1] / steps, 4)},
+             "note": "a region = the --steps block repeated until it lasts >= 100 ms, bracketed by barrier + synchronize; value is the MEDIAN region"}
+    return med, sorted(enq)[len(enq) // 2], stats
 
 
 def kernel_profile(wl, steps):
@@ -302,11 +349,19 @@ def counters_provenance(config, lanes_key=None):
     return out
 
 
-def drop_in_probe(dev):
+def _min_of(fn, reps=5):
+    best = None
+    for _ in range(reps):
+        x = fn()
+        best = x if best is None or x < best else best
+    return best
+
+
+def drop_in_probe(dev, reps=5):
     """The schedule Topo4D runs (train.py:661-673) through the UNMODIFIED drop-in: one camera per iteration, `params2rendervar`
     (the reference's five torch ops, helpers.py:91-100) -> GaussianRasterizer(raster_settings=cam)(**rendervar) -> backward with
-    a supplied dL/dcolour.  P = 8,280, 512x375, default sync mode ("auto").  Host-bound: iterations/s, and the same loop without
-    the torch ops of params2rendervar around it."""
+    a supplied dL/dcolour.  P = 8,280, 512x375, the drop-in's default sync mode.  Host-bound: iterations/s (best of `reps` runs of
+    400 iterations; the spread rides along), and the same loop without the torch ops of params2rendervar around it."""
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
     from scaffold import reference_boundary as boundary, scene
     from topo4d_amd import rasterizer
@@ -334,62 +389,287 @@ def drop_in_probe(dev):
     saved = rasterizer._save_sync_mode()
     rasterizer._restore_sync_mode(("checked", False))      # what an unmodified train.py gets: the drop-in's default mode
     out = {"workload": "1 camera per iteration, P=8280, 512x375, params2rendervar -> GaussianRasterizer -> backward (train.py:661-673)",
-           "sync_mode": "auto (drop-in default)"}
+           "sync_mode": rasterizer.get_sync_mode(drop_in=True) + " (drop-in default: un-synchronised forward, its own backward refuses the gradients of a truncated render)"}
     try:
         for name, fn in (("it_per_s", it_full), ("it_per_s_without_params2rendervar", it_raster), ("params2rendervar_only_it_per_s", it_torch_only)):
             for i in range(60):
                 fn(i)
             torch.cuda.synchronize(dev)
             n = 400
-            t0 = time.perf_counter()
-            for i in range(n):
-                fn(i)
-            torch.cuda.synchronize(dev)
-            out[name] = round(n / (time.perf_counter() - t0), 1)
+            runs = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                for i in range(n):
+                    fn(i)
+                torch.cuda.synchronize(dev)
+                runs.append(n / (time.perf_counter() - t0))
+            out[name] = round(max(runs), 1)
+            out[name + "_runs"] = [round(x, 1) for x in runs]
     finally:
         rasterizer._restore_sync_mode(saved)
     out["note"] = ("host-bound: an iteration is the reference's own torch ops (params2rendervar forward + autograd backward, "
-                   "params2rendervar_only_it_per_s) plus the drop-in call (it_per_s_without_params2rendervar); GPU time per view is single_view.gpu_us_per_view")
+                   "params2rendervar_only_it_per_s) plus the drop-in call (it_per_s_without_params2rendervar); best of the listed runs; "
+                   "GPU time per view is single_view.gpu_us_per_view")
     return out
 
 
-def single_view_probe(dev):
-    """The reference's own call shape (train.py:661-673): ONE camera per call, P = 8,280, 512x375.  GPU time per forward +
-    backward = sum of the HIP-event durations of the rasterizer's kernels; wall time per un-synchronised call pair too."""
+SHAPES = {   # small-launch probes: (n_lat, n_lon, H, W)
+    "topo4d": (69, 120, 512, 375),            # P = 8,280, helpers.py:807: (3, 512, 375) images
+    "c2": (150, 200, 512, 512),               # the config-2 scene: P = 30,000, 512 x 512
+}
+
+
+def render_probe(dev, shape, n_views, reps=5, iters=200):
+    """V views per call of a small scene through the C ABI, forward + backward: GPU time per call = sum of the HIP-event durations
+    of the rasterizer's kernels, and wall time per un-synchronised call pair; both the MINIMUM over `reps` runs of `iters` calls
+    (a single run of this probe once read 220 us where every other read 103-113: one-shot side probes are not measurements)."""
     import topo4d_amd
     from scaffold import reference_boundary as boundary, scene
     from topo4d_amd import ViewBatch, _lib, pack_views
-    H, W = 512, 375                                                    # helpers.py:807: (3, 512, 375) images
-    p = scene.make_gaussians(69, 120, opacity="A", seed=0)             # 8,280 vertex-bound Gaussians
+    n_lat, n_lon, H, W = SHAPES[shape]
+    p = scene.make_gaussians(n_lat, n_lon, opacity="A", seed=0)
     cams = scene.camera_rig(H, W, n_views=24, device=dev)
+    sel = [12] if n_views == 1 else list(range(0, 24, 24 // n_views))[:n_views]
     rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
     g = torch.Generator().manual_seed(0)
-    dc = (torch.randn(1, 3, H, W, generator=g) / (3 * H * W)).to(dev)
-    b = ViewBatch(pack_views(cams[12:13], dev), H, W)
+    dc = (torch.randn(n_views, 3, H, W, generator=g) / (3 * H * W)).to(dev)
+    b = ViewBatch(pack_views([cams[i] for i in sel], dev), H, W)
     f = lambda: (b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv["colors_precomp"]), b.backward(dc))
-    topo4d_amd.set_sync_mode("checked")
-    f()
-    topo4d_amd.set_sync_mode("lazy")
-    for _ in range(100):
+    saved = topo4d_amd.rasterizer._save_sync_mode()
+    try:
+        topo4d_amd.set_sync_mode("checked")
         f()
-    torch.cuda.synchronize(dev)
-    n = 300
-    t0 = time.perf_counter()
-    for _ in range(n):
-        f()
-    torch.cuda.synchronize(dev)
-    wall_us = 1e6 * (time.perf_counter() - t0) / n
-    _lib.profile_begin()
-    for _ in range(n):
-        f()
-    torch.cuda.synchronize(dev)
-    prof = _lib.profile_end()
-    kern = {name: round(1e3 * ms / max(cnt, 1), 2) for name, (ms, cnt) in prof.items() if cnt}
-    st = b.fetch_status()
+        topo4d_amd.set_sync_mode("lazy")
+        for _ in range(100):
+            f()
+        torch.cuda.synchronize(dev)
+        walls, gpus, kern_best = [], [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                f()
+            torch.cuda.synchronize(dev)
+            walls.append(1e6 * (time.perf_counter() - t0) / iters)
+            _lib.profile_begin()
+            for _ in range(iters):
+                f()
+            torch.cuda.synchronize(dev)
+            prof = _lib.profile_end()
+            kern = {name: round(1e3 * ms / max(cnt, 1), 2) for name, (ms, cnt) in prof.items() if cnt}
+            gpus.append(sum(kern.values()))
+            if kern_best is None or gpus[-1] <= min(gpus):
+                kern_best = kern
+        st = b.fetch_status()
+    finally:
+        topo4d_amd.rasterizer._restore_sync_mode(saved)
+    return {"views_per_call": n_views, "gpu_us_per_call": round(min(gpus), 1), "gpu_us_runs": [round(x, 1) for x in gpus],
+            "kernels_us": kern_best, "wall_us_per_call": round(min(walls), 1), "wall_us_runs": [round(x, 1) for x in walls],
+            "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs)}
+
+
+def single_view_probe(dev):
+    """The reference's own call shape (train.py:661-673): ONE camera per call, P = 8,280, 512x375."""
+    r = render_probe(dev, "topo4d", 1)
     return {"workload": "1 view per call, P=8280, 512x375 (HxW), opacity scenario A, forward+backward through the C ABI",
-            "gpu_us_per_view": round(sum(kern.values()), 1), "kernels_us": kern,
-            "wall_us_per_view_unsynchronised_calls": round(wall_us, 1), "views_per_s_wall": round(1e6 / wall_us, 1),
-            "pairs": int(st.total_pairs), "note": "gpu_us = sum of HIP-event kernel durations (launch gaps excluded)"}
+            "gpu_us_per_view": r["gpu_us_per_call"], "gpu_us_runs": r["gpu_us_runs"], "kernels_us": r["kernels_us"],
+            "wall_us_per_view_unsynchronised_calls": r["wall_us_per_call"], "wall_us_runs": r["wall_us_runs"],
+            "views_per_s_wall": round(1e6 / r["wall_us_per_call"], 1), "pairs": r["pairs"], "longest_tile_list": r["longest_tile_list"],
+            "note": "gpu_us = sum of HIP-event kernel durations; min over 5 runs of 200 calls"}
+
+
+def small_v_probe(dev):
+    """1 and 3 views of the config-2 scene per call: the launch of one rank of an 8-way view shard (24 / 8 = 3 views)."""
+    out = {"workload": "V views per call of the config-2 scene (P=30000, 512x512), forward+backward through the C ABI, lazy sync"}
+    for v in (1, 3):
+        out[f"v{v}"] = render_probe(dev, "c2", v)
+    return out
+
+
+def forecast_probe(dev, in_flight):
+    """What view sharding (BASELINE config 3: 'views sharded across 8 MI355X') would give, measured on ONE GPU: the step time of
+    24 / 12 / 6 / 3 views of the config-2 scene per launch = what one rank of a 1 / 2 / 4 / 8-way view shard runs per frame.
+    Frames of Topo4D's real loop are sequential (train.py:646), so ONE frame is in flight here; predicted strong-scaling speed-up
+    at N GPUs = t(24) / t(24 / N) (no collective cost included: the loss gather is 24 floats)."""
+    out = {"workload": "config-2 scene, V views per launch, one frame at a time (frames of the real loop are sequential)", "steps": 50}
+    t = {}
+    for v in (24, 12, 6, 3):
+        wl = Workload("C2", "A", dev, in_flight=1, n_views=v, resident=2)
+        wl.learn_capacity()
+        dt, _, st = timed_run(wl, 50, 3, 0.05, lambda: torch.cuda.synchronize(dev), lambda x: x, regions=5, min_region_s=0.05)
+        t[v] = dt / 50
+        out[f"ms_per_step_v{v}"] = st["ms_per_step"]["median"]
+        del wl
+    out["predicted_view_sharded_speedup"] = {str(n): round(t[24] / t[24 // n], 2) for n in (2, 4, 8)}
+    out["predicted_views_per_s"] = {str(n): round(24 / t[24 // n], 1) for n in (1, 2, 4, 8)}
+    return out
+
+
+def c4_probe(dev, steps=6):
+    """BASELINE config 4 (24 x 2048^2, P = 120,000, SH degree 3: 'the 1-MI355X HBM-roofline run') in the default command."""
+    wl = Workload("C4", "A", dev, in_flight=2, resident=2)
+    wl.learn_capacity()
+    dt, _, st = timed_run(wl, steps, 2, 0.1, lambda: torch.cuda.synchronize(dev), lambda x: x, regions=5, min_region_s=0.0)
+    wl.sequential = True
+    dts, _, sts = timed_run(wl, steps, 1, 0.0, lambda: torch.cuda.synchronize(dev), lambda x: x, regions=3, min_region_s=0.0)
+    wl.sequential = False
+    sts_ = wl.statuses()
+    prof, _ = kernel_profile(wl, steps)
+    cfg, V, P, H, W = wl.cfg, wl.V, wl.P, wl.H, wl.W
+    S = 3 * (cfg["sh_degree"] + 1) ** 2 * 4
+    R_view = sts_[0].total_pairs / V
+    per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, S)
+    kernels = {n: {"avg_us": round(1e3 * ms / c, 1), "alg_GBs": round(per_kernel[n] * V / (1e-3 * ms / c) / 1e9, 1)} for n, (ms, c) in prof.items() if c}
+    dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+    ach = kernels[dom]["alg_GBs"]
+    valu = load_profile_json("valu.json", "C4", dom)
+    return {"workload": f"C4: {V} views x {H}x{W}, P={P}, SH degree 3, opacity scenario A, forward+backward, per-view gradients, 2 frames in flight",
+            "steps": steps, "ms_per_step": st["ms_per_step"], "value": round(V * steps / dt, 1), "unit": "views/s",
+            "sequential_ms_per_step": sts["ms_per_step"]["median"], "pairs_per_view": int(R_view), "overflow": bool(any(x.overflow for x in sts_)),
+            "roofline": {"bound": ("valu" if valu and valu.get("valu_busy", 0) > 0.6 else "hbm"), "kernel": dom, "achieved": ach, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": load_profile_json("traffic.json", "C4", dom),
+                         "alg_bytes_per_launch": int(per_kernel[dom] * V), "avg_us": kernels[dom]["avg_us"], "kernels": kernels,
+                         "pipeline_alg_bytes_per_view": int(total_bytes),
+                         "pipeline_frac_of_peak": round(V * steps / dt * total_bytes / 1e9 / PEAK_HBM_GBS, 4),
+                         "counters": counters_provenance("C4")}}
+
+
+def dense_1m_probe(dev, reps=5):
+    """Topo4D's texture pass shape (train.py:729-741, params2rendervar_dense): ONE view per call, P = 10^6 at 4096 x 3008."""
+    import topo4d_amd
+    from scaffold import reference_boundary as boundary, scene
+    from topo4d_amd import ViewBatch, _lib, pack_views
+    H, W = 3008, 4096
+    p = scene.make_gaussians(1000, 1000, opacity="A", seed=0)
+    cams = scene.camera_rig(H, W, n_views=24, device=dev)[12:13]
+    rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
+    dc = torch.randn(1, 3, H, W, device=dev) / (3 * H * W)
+    b = ViewBatch(pack_views(cams, dev), H, W)
+    f = lambda: (b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv["colors_precomp"]), b.backward(dc))
+    saved = topo4d_amd.rasterizer._save_sync_mode()
+    try:
+        topo4d_amd.set_sync_mode("checked")
+        f()
+        st = b.fetch_status()
+        topo4d_amd.set_sync_mode("lazy")
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize(dev)
+        walls = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                f()
+            torch.cuda.synchronize(dev)
+            walls.append(1e3 * (time.perf_counter() - t0) / 10)
+        _lib.profile_begin()
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize(dev)
+        kern = {n: round(1e3 * ms / c, 1) for n, (ms, c) in _lib.profile_end().items() if c}
+    finally:
+        topo4d_amd.rasterizer._restore_sync_mode(saved)
+    return {"workload": "1 view per call, P=1000000, 4096x3008 (WxH), opacity scenario A, forward+backward through the C ABI",
+            "ms_per_view": round(min(walls), 3), "ms_runs": [round(x, 3) for x in walls], "views_per_s": round(1e3 / min(walls), 1),
+            "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs), "kernels_us": kern}
+
+
+def full_iteration_probe(dev, reps=5):
+    """The whole optimisation iteration around the rasterizer (train.py:661-700): activations -> render -> photometric loss ->
+    backward -> Adam + region pins, on the fused pieces.  V = 1 (the reference's schedule: one camera per iteration, P = 8,280,
+    512x375) eagerly and replayed from one HIP graph per camera; V = 24 (all cameras of a frame in one launch set, config-2
+    scene, one Adam step per frame)."""
+    from scaffold import scene
+    from topo4d_amd import loop as t4d_loop, loss as t4d_loss, rasterize_views
+    from topo4d_amd.boundary import params2rendervar_fused
+    from topo4d_amd.optim import FusedAdamPins
+    import topo4d_amd
+    out = {}
+    g = torch.Generator().manual_seed(0)
+
+    def setup(n_lat, n_lon, H, W, capturable):
+        p = scene.make_gaussians(n_lat, n_lon, opacity="A", seed=0)
+        params = {k: torch.nn.Parameter(v.to(dev)) for k, v in p.items()}
+        P = params["means3D"].shape[0]
+        opt = FusedAdamPins([{"params": [v], "name": k, "lr": 1e-5} for k, v in params.items()], eps=1e-15, capturable=capturable)
+        opt.set_pin("means3D", torch.arange(0, P, 5), params["means3D"][::5].detach().clone())      # a "static region" (train.py:676-700)
+        cams = scene.camera_rig(H, W, n_views=24, device=dev)
+        gts = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(24)]
+        return params, opt, cams, gts
+
+    saved = topo4d_amd.rasterizer._save_sync_mode()
+    try:
+        # ---- V = 1, eager (drop-in default sync mode) and graphed
+        topo4d_amd.rasterizer._restore_sync_mode(("checked", False))
+        params, opt, cams, gts = setup(69, 120, 512, 375, False)
+        data = [{"cam": cams[i], "im": gts[i], "id": i} for i in range(24)]
+
+        def it_eager(i):
+            l, _, _ = t4d_loop.photometric_iteration(params, data[i % 24])
+            l.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        for i in range(48):
+            it_eager(i)
+        torch.cuda.synchronize(dev)
+        runs = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for i in range(300):
+                it_eager(i)
+            torch.cuda.synchronize(dev)
+            runs.append(300 / (time.perf_counter() - t0))
+        out["v1_eager_it_per_s"] = round(max(runs), 1)
+        out["v1_eager_runs"] = [round(x, 1) for x in runs]
+        gparams, gopt, cams, gts = setup(69, 120, 512, 375, True)
+        gdata = [{"cam": cams[i], "im": gts[i], "id": i} for i in range(24)]
+        gv = t4d_loop.GraphedViews(gparams, gdata, gopt)
+        for i in range(48):
+            gv.step(i % 24)
+        torch.cuda.synchronize(dev)
+        runs = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for i in range(1000):
+                gv.step(i % 24)
+            torch.cuda.synchronize(dev)
+            runs.append(1000 / (time.perf_counter() - t0))
+        gv.check()
+        out["v1_graphed_it_per_s"] = round(max(runs), 1)
+        out["v1_graphed_runs"] = [round(x, 1) for x in runs]
+        out["v1_graphed_us_per_iteration"] = round(1e6 / max(runs), 1)
+        del gv
+        # ---- V = 24: one launch set per frame
+        topo4d_amd.set_sync_mode("checked")
+        params, opt, cams, gts = setup(150, 200, 512, 512, False)
+        gt = torch.stack(gts)
+
+        def it_frame():
+            rv = params2rendervar_fused(params)
+            im, radii, _, _ = rasterize_views(cams, rv["means3D"], rv["means2D"], rv["opacities"], colors_precomp=rv["colors_precomp"],
+                                              scales=rv["scales"], rotations=rv["rotations"])
+            t4d_loss.photometric_loss(im, gt).sum().backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        it_frame()
+        topo4d_amd.set_sync_mode("lazy")
+        for _ in range(10):
+            it_frame()
+        torch.cuda.synchronize(dev)
+        runs = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(50):
+                it_frame()
+            torch.cuda.synchronize(dev)
+            runs.append(1e3 * (time.perf_counter() - t0) / 50)
+        out["v24_ms_per_frame_iteration"] = round(min(runs), 4)
+        out["v24_runs_ms"] = [round(x, 4) for x in runs]
+        out["v24_views_per_s"] = round(24e3 / min(runs), 1)
+    finally:
+        topo4d_amd.rasterizer._restore_sync_mode(saved)
+    out["workload"] = ("params2rendervar (fused activations) -> render -> fused photometric loss (L1 + SSIM) -> backward -> fused Adam + pins; "
+                       "v1: P=8280, 512x375, one camera per iteration (train.py:661-700); v24: config-2 scene, 24 cameras per launch set, view-summed gradients, one Adam step per frame")
+    return out
 
 
 def main():
@@ -402,6 +682,10 @@ def main():
     ap.add_argument("--config", default="C2", choices=["C2", "C4"])
     ap.add_argument("--opacity", default="A", choices=["A", "B"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--shard", default="frames", choices=["frames", "views"],
+                    help="frames: rank r renders frames r, r+N, ... (24 views each); views: every rank steps through all frames and "
+                         "renders views r::N of each (strong scaling of ONE frame: the split Topo4D's sequential frames allow)")
+    ap.add_argument("--allreduce-grads", action="store_true", help="--shard views: sum the view-summed parameter gradients over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the scenario-B and single-view side measurements")
     ap.add_argument("--cpu-sample-views", type=int, default=0)
@@ -449,9 +733,18 @@ def main():
         # config 2: 0.430 / 0.425 / 0.433 ms with 2 / 3 / 4 frames in flight; config 4: 4.06 / 4.10 ms with 2 / 3 (one: 4.20) - end of
         # round 3, same box; `sequential` in the JSON line is the same steps one frame at a time
         args.in_flight = 3 if args.config == "C2" else 2
-    wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)
+    by_views = args.shard == "views"
+    if by_views:
+        # one frame is in flight: the frames of the loop this split serves are sequential (train.py:646)
+        args.scaling, args.in_flight = "strong", 1
+        wl = Workload(args.config, args.opacity, dev, rank, world, 1, gather=dist is not None, view_shard=(rank, world),
+                      allreduce_grads=args.allreduce_grads)
+    else:
+        wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
-    my_steps = strong_steps_per_rank if args.scaling == "strong" else args.steps
+    my_steps = args.steps if by_views else (strong_steps_per_rank if args.scaling == "strong" else args.steps)
+    # views per step over ALL ranks: a view-sharded step is one whole frame; a frame-sharded step is one frame per rank
+    views_per_step_job = wl.full_views if by_views else V * world
 
     def barrier():
         wl.drain()
@@ -469,23 +762,25 @@ def main():
         return float(t.item())
 
     wl.learn_capacity()
-    dt, t_enqueue = timed_run(wl, my_steps, args.warmup, args.prewarm_s, barrier, all_reduce_max)
+    dt, t_enqueue, repeats = timed_run(wl, my_steps, args.warmup, args.prewarm_s, barrier, all_reduce_max)
     sequential = None
     if wl.F > 1:                     # the same steps, one frame after the other on one stream: what the overlap is worth
         wl.sequential = True
-        dts, _ = timed_run(wl, my_steps, args.warmup, 0.05, barrier, all_reduce_max)
+        dts, _, sts_seq = timed_run(wl, my_steps, args.warmup, 0.05, barrier, all_reduce_max)
         wl.sequential = False
-        sequential = {"ms_per_step": round(1e3 * dts / my_steps, 4), "value": round(V * my_steps * world / dts, 2), "unit": "views/s",
+        sequential = {"ms_per_step": round(1e3 * dts / my_steps, 4), "value": round(views_per_step_job * my_steps / dts, 2), "unit": "views/s",
+                      "ms_per_step_min_median_max": sts_seq["ms_per_step"], "regions": sts_seq["regions"], "steps_per_region": sts_seq["steps_per_region"],
                       "note": "frames_in_flight = 1: the same steps one after the other on one stream"}
     # The OTHER scaling mode in the same line: the driver's one command per N must yield both the weak figure (`value`) and the
     # number north_star asks for - the fixed 64-frame job of BASELINE config 3 split over the ranks (strong scaling).
     other = None
-    if args.config == "C2":
+    if args.config == "C2" and not by_views:
         o_steps = 20 if args.scaling == "strong" else max(1, min(strong_steps_per_rank, 512))
-        dto, _ = timed_run(wl, o_steps, min(args.warmup, 2), 0.05, barrier, all_reduce_max)
+        dto, _, sto = timed_run(wl, o_steps, min(args.warmup, 2), 0.05, barrier, all_reduce_max, regions=3,
+                                min_region_s=(0.0 if args.scaling == "weak" else MIN_REGION_S))
         if args.scaling == "weak":
             other = {"scaling": "strong", "job_frame_steps": o_steps * world, "steps_per_rank": o_steps,
-                     "ms_job": round(1e3 * dto, 4), "value": round(V * o_steps * world / dto, 2), "unit": "views/s",
+                     "ms_job": round(1e3 * dto, 4), "value": round(V * o_steps * world / dto, 2), "unit": "views/s", "regions": sto["regions"],
                      "note": f"fixed job: the {STRONG_JOB_FRAMES}-frame sequence of config 3 (rounded up to a whole number of frames "
                              "per rank), sharded by frame; strong-scaling speed-up at N GPUs = this value at N / this value at 1"}
         else:
@@ -496,14 +791,17 @@ def main():
         raise SystemExit("pair arena overflowed during the timed region: result invalid")
     total_pairs_all = sts[0].total_pairs
     # T4D_BENCH_DUMP_LOSSES=k (tests): the gathered per-view loss vectors of this rank's first k steps go into the JSON line
-    last_losses = None
+    last_losses = grad_sums = None
     if os.environ.get("T4D_BENCH_DUMP_LOSSES"):
-        last_losses = []
+        last_losses, grad_sums = [], []
         for i in range(int(os.environ["T4D_BENCH_DUMP_LOSSES"])):
-            o, _ = wl.step(i)
+            o, gs = wl.step(i)
             wl.drain()
             torch.cuda.synchronize(dev)
             last_losses.append(o.detach().float().cpu().tolist())
+            # one float64 checksum per view of THIS rank over all its gradient tensors (tests: a view's gradients do not depend
+            # on which other views share its launch)
+            grad_sums.append(sum(t.double().reshape(t.shape[0], -1).sum(1) for t in gs[0].values() if t is not None).cpu().tolist())
     barrier()
 
     # ---- per-kernel durations with HIP events (same steps again; keeps `value` free of event overhead) ----
@@ -549,28 +847,61 @@ def main():
     if dist is not None:
         barrier()
 
-    # ---- side measurements on one GPU: scenario B (unsaturated opacities) and the reference's one-view-per-call shape ----
-    scenario_b = single_view = drop_in = None
+    # ---- the view-sharded split, executed (all ranks): rank r renders views r::N of EVERY frame, one frame at a time ----
+    view_sharded = None
+    if not by_views and not args.no_extras and args.config == "C2":
+        wv = Workload(args.config, args.opacity, dev, rank, world, 1, gather=dist is not None, view_shard=(rank, world), resident=4)
+        wv.learn_capacity()
+
+        def barrier_v():
+            wv.drain()
+            if dist is not None:
+                dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
+            torch.cuda.synchronize(dev)
+        dtv, _, stv = timed_run(wv, 50, 3, 0.05, barrier_v, all_reduce_max, regions=5, min_region_s=0.05)
+        view_sharded = {"parallelism": f"view-sharded x{world}: rank r renders views r::{world} of every frame ({wv.V} views per rank and frame), "
+                                       "loss all_gather per frame, one frame in flight (frames of the real loop are sequential, train.py:646)",
+                        "scaling": "strong", "views_per_rank": wv.V, "ms_per_frame": stv["ms_per_step"], "value": round(wv.full_views * 50 / dtv, 2),
+                        "unit": "views/s", "note": "strong-scaling speed-up at N GPUs = this value at N / this value at 1; the N = 1 line's `forecast` predicts it"}
+        del wv
+
+    # ---- side measurements on one GPU ----
+    scenario_b = single_view = drop_in = small_v = forecast = c4 = dense_1m = full_iteration = None
     if world == 1 and not args.no_extras:
-        try:
-            if args.opacity == "A":
+        def guarded(fn, *a):
+            try:                        # side measurements must never take the headline number down with them
+                return fn(*a)
+            except Exception as e:
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                topo4d_amd.set_sync_mode("lazy")
+                torch.cuda.synchronize(dev)
+        if args.opacity == "A":
+            def scen_b():
                 wb = Workload(args.config, "B", dev, in_flight=args.in_flight)
                 wb.learn_capacity()
-                dtb, _ = timed_run(wb, my_steps, args.warmup, 0.1, lambda: torch.cuda.synchronize(dev), lambda x: x)
+                dtb, _, stb_ = timed_run(wb, my_steps, args.warmup, 0.1, lambda: torch.cuda.synchronize(dev), lambda x: x)
                 stb = wb.statuses()
-                scenario_b = {"value": round(V * my_steps / dtb, 2), "unit": "views/s", "ms_per_step": round(1e3 * dtb / my_steps, 4),
-                              "steps": my_steps, "pairs_per_view": int(stb[0].total_pairs / V),
-                              "overflow": bool(any(x.overflow for x in stb)),
-                              "workload": "same as config.workload with opacity scenario B: uniform(0.05, 0.95)"}
-                del wb
-            single_view = single_view_probe(dev)
-            drop_in = drop_in_probe(dev)
-        except Exception as e:          # side measurements must never take the headline number down with them
-            scenario_b = scenario_b or {"error": str(e)}
-        topo4d_amd.set_sync_mode("lazy")
+                return {"value": round(V * my_steps / dtb, 2), "unit": "views/s", "ms_per_step": round(1e3 * dtb / my_steps, 4),
+                        "ms_per_step_min_median_max": stb_["ms_per_step"], "steps": my_steps, "pairs_per_view": int(stb[0].total_pairs / V),
+                        "overflow": bool(any(x.overflow for x in stb)),
+                        "workload": "same as config.workload with opacity scenario B: uniform(0.05, 0.95)"}
+            scenario_b = guarded(scen_b)
+        single_view = guarded(single_view_probe, dev)
+        drop_in = guarded(drop_in_probe, dev)
+        if args.config == "C2":
+            small_v = guarded(small_v_probe, dev)
+            forecast = guarded(forecast_probe, dev, args.in_flight)
+            full_iteration = guarded(full_iteration_probe, dev)
+            del wl.batches, wl.rv_frames
+            torch.cuda.empty_cache()
+            c4 = guarded(c4_probe, dev)
+            torch.cuda.empty_cache()
+            dense_1m = guarded(dense_1m_probe, dev)
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        views_total = V * my_steps * world
+        views_total = views_per_step_job * my_steps
         value = views_total / dt
         if roofline is not None:
             roofline["pipeline_frac_of_peak"] = round(value / world * total_bytes / 1e9 / PEAK_HBM_GBS, 4)
@@ -584,22 +915,26 @@ def main():
                 cpu = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         out = {
             "metric": "rasterizer fwd+bwd views/sec", "value": round(value, 2), "unit": "views/s",
-            "n_gpus": world, "steps": (my_steps * world if args.scaling == "strong" else args.steps), "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / my_steps, 4), "higher_is_better": True, "scaling": args.scaling,
+            "n_gpus": world, "steps": (my_steps * world if (args.scaling == "strong" and not by_views) else args.steps), "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / my_steps, 4), "higher_is_better": True, "scaling": args.scaling, "repeats": repeats,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {V} views x {H}x{W}, P={P} vertex-bound Gaussians, "
                                    f"{'SH degree %d' % cfg['sh_degree'] if cfg['sh_degree'] is not None else 'precomputed RGB'}, "
                                    f"opacity scenario {args.opacity}, forward+backward, per-view gradients",
                        "views_per_step_per_gpu": V, "frames": wl.n_frames, "steps_per_rank": my_steps,
-                       "parallelism": f"frame-sharded x{world}",
+                       "parallelism": (f"view-sharded x{world}: rank r renders views r::{world} of every frame" +
+                                       (", parameter gradients all-reduced" if args.allreduce_grads else "")) if by_views else f"frame-sharded x{world}",
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
                        "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "frames_in_flight": wl.F},
-            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "drop_in": drop_in, "sequential": sequential,
-            ("weak" if args.scaling == "strong" else "strong"): other,
+            "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "small_v": small_v,
+            "forecast": forecast, "view_sharded": view_sharded, "drop_in": drop_in, "full_iteration": full_iteration, "c4": c4,
+            "dense_1m": dense_1m, "sequential": sequential,
+            ("weak" if (args.scaling == "strong" and not by_views) else "strong"): other,
             "dist_backend": (dist.get_backend() if dist is not None else None),
         }
         if last_losses is not None:
-            out["gathered_losses_first_steps"] = last_losses
+            out["gathered_losses_first_steps"] = last_losses       # rank-major: out.view(world, -1).t() is view order in --shard views
+            out["grad_checksums_first_steps_rank0"] = grad_sums
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

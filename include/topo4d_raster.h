@@ -62,9 +62,12 @@ enum {
     T4D_FLAG_ASYNC_STATUS = 8u,/* forward, without CHECKED: `status` must point at PINNED host memory; the first 16 bytes
                                   receive { uint32 overflow; uint32 max_pairs_per_view; uint64 total_pairs } by an
                                   asynchronous copy enqueued behind the binning kernels — no host synchronisation */
-    T4D_FLAG_NO_LONG_BINS = 16u/* forward: the caller knows (T4DStatus.max_tile_pairs of an earlier call on this scene) that no
+    T4D_FLAG_NO_LONG_BINS = 16u,/* forward: the caller knows (T4DStatus.max_tile_pairs of an earlier call on this scene) that no
                                   tile list exceeds 2048 pairs: the launch of the long-bin sort kernel is skipped.  Only a
                                   speed hint — longer bins that show up anyway are still sorted correctly, just slowly */
+    T4D_FLAG_SHORT_BINS = 32u  /* forward: ... and that none exceeds 512 pairs (the one-pass ranking sort): a small launch then
+                                  sorts every bin inside the render workgroup of its tile instead of launching a sort kernel.
+                                  A speed hint like the one above */
 };
 
 typedef struct T4DProblem {

@@ -26,9 +26,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(params=["throughput", "latency"])
+@pytest.fixture(params=["throughput", "latency", "segments"])
 def render_build(request, monkeypatch):
-    """Runs a test once with each build of the per-tile render kernels (csrc/t4d_raster.hip: LAT = false / true), whatever
-    the launch size would have picked."""
-    monkeypatch.setenv("T4D_LATENCY_TILES", "0" if request.param == "throughput" else "1000000000")
+    """Runs a test once with each way the per-tile render kernels can run (csrc/t4d_raster.hip), whatever the launch size would
+    have picked: "throughput" = LAT false, whole tiles in the backward (what a 24-view launch runs); "latency" = LAT true with
+    the depth-segmented backward (what a one-view call runs); "segments" = LAT false with the segmented backward (2-4 views)."""
+    monkeypatch.setenv("T4D_LATENCY_TILES", "1000000000" if request.param == "latency" else "0")
+    if request.param == "throughput":
+        monkeypatch.setenv("T4D_NO_SEGMENTS", "1")
+    else:
+        monkeypatch.delenv("T4D_NO_SEGMENTS", raising=False)
     return request.param

@@ -87,6 +87,35 @@ def test_rccl_branch_with_a_process_group_of_one_rank():
                                   np.asarray(plain["gathered_losses_first_steps"], np.float32))
 
 
+def test_view_sharded_two_rank_dry_run_equals_the_24_view_launch():
+    """`bench.py --shard views` (the split of SURVEY 8e / BASELINE config 3: rank r renders views r::N of every frame): two ranks
+    share the test GPU, gloo stands in for RCCL.  A view's loss scalar and its gradients do not depend on which other views
+    share its launch, so the gathered per-view losses of the two 12-view launches equal those of the one 24-view launch bit for
+    bit, and so do rank 0's per-view gradient checksums (views 0, 2, 4, ...).  The same command with ONE RCCL rank runs too."""
+    common = ["--steps", "2", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--shard", "views"]
+    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="2")
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common, env)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="2"))
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "view-sharded x2" in two["config"]["parallelism"]
+    assert two["config"]["views_per_step_per_gpu"] == 12 and one["config"]["views_per_step_per_gpu"] == 24
+    l2 = np.asarray(two["gathered_losses_first_steps"], np.float32)          # [step, rank-major 2 x 12]
+    l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [step, 24]
+    np.testing.assert_array_equal(l2.reshape(2, 2, 12).transpose(0, 2, 1).reshape(2, 24), l1)
+    g2 = np.asarray(two["grad_checksums_first_steps_rank0"], np.float64)     # rank 0's views: 0, 2, 4, ...
+    g1 = np.asarray(one["grad_checksums_first_steps_rank0"], np.float64)
+    np.testing.assert_array_equal(g2, g1[:, 0::2])
+    assert np.isfinite(l1).all() and np.abs(l1).max() > 0 and np.abs(g1).max() > 0
+    # views/s counts whole frames: 24 views per step over all ranks
+    assert abs(two["value"] - 24 * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-3 * two["value"]
+    # the RCCL branch of the same command, one rank, with the optional gradient all-reduce
+    rccl = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--allreduce-grads"] + common,
+                dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_DIST_BACKEND="nccl", T4D_BENCH_DUMP_LOSSES="2", T4D_FORCE_COLLECTIVES="1"))
+    assert rccl["dist_backend"] == "nccl" and "all-reduced" in rccl["config"]["parallelism"]
+    np.testing.assert_array_equal(np.asarray(rccl["gathered_losses_first_steps"], np.float32), l1)
+
+
 def test_strong_scaling_rounds_the_job_up_to_whole_steps_per_rank():
     """`--scaling strong --steps 7` on two ranks: 4 frame-steps per rank (8 in total), not an exit."""
     env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -378,6 +378,48 @@ def test_latency_and_throughput_builds_agree(monkeypatch):
             assert np.abs(a[1][k].astype(np.float64) - b[1][k]).max() <= 2e-6 * scale + 1e-12, k
 
 
+@pytest.mark.parametrize("with_depth_alpha", [False, True])
+def test_segmented_backward_agrees_with_the_whole_tile_replay(with_depth_alpha, monkeypatch):
+    """Small launches cut the backward along depth (kSeg = 128 list positions per work item) and start every segment from the
+    forward's snapshot of the blend state instead of from the replay of everything behind it.  Lists of up to ~1,500 pairs,
+    unsaturated opacities (pixels read deep into them), a background: the segmented backward of both builds against the
+    whole-tile replay (same decisions, sums rounded differently) and against the C oracle."""
+    H, W, V = 64, 48, 2
+    rv, cams = util.make_scene(60, 100, H, W, V, opacity="B", seed=43)
+    rv["opacities"] = rv["opacities"] * 0.15                        # thin splats: the replay runs through hundreds of them
+    rv["scales"] = rv["scales"] * 2.0
+    cams = [c._replace(bg=torch.tensor([0.3, 0.5, 0.2])) for c in cams]
+    from scaffold import scene
+    dc, dd, da = scene.output_cotangents(V, H, W, seed=44, depth_alpha=True)
+    if not with_depth_alpha:
+        dd = da = None
+    res = {}
+    for name, lat, noseg in (("whole", "0", "1"), ("segments", "0", None), ("latency-segments", "1000000000", None)):
+        monkeypatch.setenv("T4D_LATENCY_TILES", lat)
+        if noseg:
+            monkeypatch.setenv("T4D_NO_SEGMENTS", noseg)
+        else:
+            monkeypatch.delenv("T4D_NO_SEGMENTS", raising=False)
+        out, g, batch = util.hip_render(cams, rv, dc, dd, da)
+        res[name] = (out, g, util.decode_state(batch))
+    st = res["whole"][2]
+    assert st["tile_count"].max() > 4 * 128                         # several segments per tile ...
+    assert (st["n_contrib"] > 3 * 128).any()                        # ... and pixels that read beyond the third boundary
+    a = res["whole"]
+    for name in ("segments", "latency-segments"):
+        b = res[name]
+        for k in a[0]:
+            np.testing.assert_array_equal(a[0][k], b[0][k])         # the forward is the same program per pixel
+        for k in a[1]:
+            if a[1][k] is not None:
+                scale = np.abs(a[1][k]).max()
+                assert np.abs(a[1][k].astype(np.float64) - b[1][k]).max() <= 2e-5 * scale + 1e-12, (name, k)
+    for v in range(V):
+        r, g = util.c_oracle_render(cams[v], rv, dc[v], None if dd is None else dd[v], None if da is None else da[v])
+        for name in ("segments", "latency-segments"):
+            check_grads(res[name][1], g, v)
+
+
 def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
     """Mesh order is what makes the LDS tile histogram of k_preprocess effective; a random permutation at 1024^2 makes
     every workgroup's tile bounding box larger than the histogram, so the per-pair global-atomic fallback runs."""

@@ -73,6 +73,17 @@ constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (boundi
 constexpr int kBuckets = 24;         // tile-length classes (floor(log2 n), descending; last = empty) for launch ordering
 constexpr int kGP = T4D_GRAD_PAIR_FLOATS;
 constexpr int kCursorSegs = 8;       // pair-slot cursors per view (same-address returning atomics are serial: see k_preprocess)
+// Small launches (the reference's own call shape: ONE view per call, train.py:661-673; a view-sharded rank: three views) cannot
+// fill the chip with whole tiles: a kernel lasts as long as its LONGEST tile list is walked by one workgroup.  For launches of
+// at most kSegMaxTiles tiles the backward is therefore cut along DEPTH: a tile list of n pairs becomes ceil(n / kSeg)
+// independent work items.  What makes them independent is kept by the forward: the per-pixel blend state (T, C, D) at every
+// kSeg-th list position (a "snapshot", 20 bytes per pixel and boundary) - the backward's replay of positions [j kSeg, (j+1) kSeg)
+// starts from the transmittance in front of position (j+1) kSeg and from the suffix colour (C_final - C_prefix) / T, both taken
+// from the snapshots instead of from the replay of everything behind.  No running value of the replay feeds a discrete
+// decision, so the segments take the decisions of the whole-list replay; sums differ by rounding only.
+constexpr int kSeg = 128;            // list positions per backward segment (= kBwdBatch: one staged batch per segment)
+constexpr int kSegMaxTiles = 8192;   // launches of at most this many tiles (V * T) run the segmented backward
+constexpr int kSnapFloats = 5;       // T, C0, C1, C2, D per pixel and boundary
 
 thread_local char g_err[512] = "";
 
@@ -88,7 +99,8 @@ std::vector<ProfRec> g_prof;
 // state / scratch layout
 // ---------------------------------------------------------------------------------------------------------
 struct Layout {
-    size_t status, view_total, view_cursor, tile_count, bucket_fill, zero_end;
+    size_t status, view_total, view_cursor, tile_count, bucket_fill, slot_tab, zero_end;
+    size_t snap;
     size_t tile_off, chunk_sum, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, sort_tmp, final_T, n_contrib, total;
 };
 
@@ -100,6 +112,17 @@ struct DevStatus {            // first bytes of the state buffer
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// segmented backward (see kSeg): decided by the problem's dimensions alone, so that t4d_state_bytes, the forward and the
+// backward of a call agree without talking to each other
+inline bool seg_capable(const T4DProblem &p)
+{
+    const long long T = (long long)((p.W + T4D_TILE_X - 1) / T4D_TILE_X) * (long long)((p.H + T4D_TILE_Y - 1) / T4D_TILE_Y);
+    return (long long)p.n_views * T <= kSegMaxTiles;
+}
+// Segment slots of a view.  Tile t (arena offset off, n pairs) owns the slots floor(off / kSeg) + t ... + ceil(n / kSeg) - 1:
+// disjoint from tile to tile ((off + n) / kSeg - off / kSeg >= floor(n / kSeg)) without a prefix sum over the tiles.
+inline size_t seg_slots_per_view(const T4DProblem &p, size_t T) { return (size_t)p.pair_capacity / kSeg + T + 1; }
 
 Layout make_layout(const T4DProblem &p)
 {
@@ -114,7 +137,10 @@ Layout make_layout(const T4DProblem &p)
     L.view_cursor = o;   o = align_up(o + V * kCursorSegs * 4);
     L.tile_count = o;    o = align_up(o + V * T * 4);
     L.bucket_fill = o;   o = align_up(o + kBuckets * 4);
+    const size_t slots = seg_capable(p) ? V * seg_slots_per_view(p, T) : 0;
+    L.slot_tab = o;      o = align_up(o + slots * 16);           // (zeroed with the counters: an all-zero entry is "no segment")
     L.zero_end = o;
+    L.snap = o;          o = align_up(o + slots * kSnapFloats * kBlock * 4);
     L.tile_off = o;      o = align_up(o + V * T * 4);
     L.chunk_sum = o;     o = align_up(o + V * ((T + kScanChunk - 1) / kScanChunk) * 4);
     L.order = o;         o = align_up(o + (size_t)kBuckets * V * T * 4);
@@ -170,6 +196,11 @@ struct KP {
     uint32_t tile_blocks;    // k_render_bwd / k_render_fwd: workgroups that walk the tile list (the backward's others do the empty tiles' dots)
     uint32_t fill_blocks;    // k_render_fwd: workgroups that write the EMPTY tiles' pixels, one per (view, row of tiles)
     uint32_t fill_vec;       // ... with 16-byte stores (W % 4 == 0 and 16-byte aligned output planes)
+    // segmented backward of small launches (kSeg): slot table (id, arena offset, n, segment | 1 << 31) and forward snapshots
+    uint4 *slot_tab;
+    float *snap;             // [V * slots_per_view][kSnapFloats][256]
+    uint32_t slots_per_view; // 0: this launch is not segmented
+    uint32_t fused_sort;     // k_render_fwd<LAT = true> sorts its tile's bin itself (no k_sort_tiles launch)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -699,6 +730,15 @@ __global__ __launch_bounds__(kScanChunk) void k_scan_tiles(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 // A.2 scatter keys into tile bins
 // ---------------------------------------------------------------------------------------------------------
+// segmented backward (kSeg): one slot-table entry per kSeg list positions of a tile, at the slots the tile owns
+__device__ __forceinline__ void write_segment_slots(const KP &kp, const uint32_t id, const uint32_t off, const uint32_t n)
+{
+    if (kp.slots_per_view == 0u || n == 0u) return;
+    const uint32_t nseg = (n + kSeg - 1) / kSeg;
+    uint4 *tab = kp.slot_tab + (size_t)(id >> 20) * kp.slots_per_view + off / kSeg + (id & 0xfffffu);
+    for (uint32_t j = 0; j < nseg; j++) tab[j] = make_uint4(id, off, n, j | 0x80000000u);
+}
+
 __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
 {
     // One launch index: V * nb8 scatter workgroups (nb8 = blocks of 256 Gaussians, rounded up to eight), view after view in block
@@ -719,6 +759,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
         const uint32_t off = kp.tile_off[vt];
         const uint32_t n = off >= kp.cap ? 0u : min(kp.tile_count[vt], kp.cap - off);
         kp.items[b] = make_uint4(id, off, n, kp.tile_count[vt]);       // .w = 0: a truly empty tile (n = 0 also after an arena overflow)
+        write_segment_slots(kp, id, off, n);
         return;
     }
     const int v = (int)(blockIdx.x / nb8);
@@ -810,6 +851,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
                 kp.tile_off[t] = off[j];
                 const uint32_t n = off[j] >= kp.cap ? 0u : min(c[j], kp.cap - off[j]);
                 kp.items[s_bpre[bk[j]] + rank[j]] = make_uint4((uint32_t)t, off[j], n, c[j]);       // view 0: id = tile
+                write_segment_slots(kp, (uint32_t)t, off[j], n);
             }
         }
         if (tid == 0) {
@@ -982,13 +1024,72 @@ __device__ __forceinline__ void sort_bin_chunked(unsigned long long *keys, unsig
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
+// One bin of n keys, sorted by the whole workgroup (BLOCK threads) through s_keys (kSortLdsCap keys).  KEEP: leave the sorted keys
+// in s_keys[0, n) as well (n <= kSortLdsCap) - the latency build of k_render_fwd sorts its own tile's bin and stages from there.
+template <bool KEEP, int BLOCK>
+__device__ __forceinline__ void sort_one_bin(const KP &kp, const int v, const uint32_t off, const uint32_t n, unsigned long long *s_keys,
+                                             const int tid, const int wave, const int lane)
 {
+    unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
+    if (n <= (uint32_t)kRankSortMax) {
+        // Runs of 64 keys are sorted inside a wave's registers (no LDS, no barrier); a key's final position is its
+        // position in its own run plus, for every other run, the number of keys smaller than it (keys are unique: the
+        // Gaussian index is the low word).  One barrier per tile, 7 dependent LDS reads per (key, other run).
+        constexpr int kWaves = BLOCK / 64;
+        constexpr int kPer = kRankSortMax / BLOCK > 0 ? kRankSortMax / BLOCK : 1;      // keys per thread
+        const uint32_t runs = (n + 63u) >> 6;
+        unsigned long long mine[kPer];
+        uint32_t ranks[kPer];
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const uint32_t i = (uint32_t)tid + e * BLOCK;      // run (wave + kWaves e), position lane
+            if ((uint32_t)(wave + kWaves * e) < runs) {        // wave-uniform
+                mine[e] = i < n ? keys[i] : ~0ull;             // the last run is padded with +inf
+                wave_sort64(mine[e], lane);
+                s_keys[i] = mine[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const uint32_t own = (uint32_t)(wave + kWaves * e);
+            ranks[e] = 0xffffffffu;
+            if (own < runs) {
+                uint32_t rank = (uint32_t)lane;
+#pragma unroll
+                for (uint32_t r = 0; r < (uint32_t)(kRankSortMax / 64); r++)      // unrolled: the searches overlap
+                    if (r < runs && r != own) rank += run_lower_bound(s_keys + ((r % kWaves) * 64u + (r / kWaves) * BLOCK), mine[e]);
+                if (mine[e] != ~0ull) { keys[rank] = mine[e]; ranks[e] = rank; }
+            }
+        }
+        if (KEEP) {
+            __syncthreads();                                   // every search has read the runs: they may be overwritten
+#pragma unroll
+            for (int e = 0; e < kPer; e++)
+                if (ranks[e] != 0xffffffffu) s_keys[ranks[e]] = mine[e];
+        }
+    } else if (n <= (uint32_t)kSortLdsCap) {
+        sort_chunk_lds<BLOCK, kSortLdsCap>(keys, n, s_keys, tid, wave, lane);
+    } else if (!kp.long_bins_elsewhere) {
+        // only when the host said that no such bin exists (T4D_FLAG_NO_LONG_BINS) and one appeared nevertheless:
+        // correct, but one workgroup per bin with 16 KiB of LDS - k_sort_long is the fast path
+        sort_bin_chunked<BLOCK, kSortLdsCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
+    }
+}
+
+// BLOCK = 256: the throughput build (a 24-view launch holds thousands of bins: four waves per bin keep every SIMD busy).
+// BLOCK = 1024: small launches (at most kSegMaxTiles tiles), whose sort lasts as long as its LONGEST bin takes one workgroup:
+// a lone wave issues an instruction every four cycles, so a bin of 1,286 keys took 28 us on four waves (six register sorts of
+// ~1 us and 5 merge levels of ~3 us per wave: tools/micro/sort_bin.hip); sixteen waves share that work.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sort_tiles(const KP kp)
+{
+    constexpr int kWaves = BLOCK / 64;
     __shared__ unsigned long long s_keys[kSortLdsCap];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Work units.  The item list is ordered by length class (floor(log2 n), descending), and bucket_fill holds the size of every
     // class: bins of 64 keys and more are one unit per workgroup; bins of 2..63 keys fit one register-sorted run, need neither LDS
-    // nor a barrier, and go FOUR to a unit, one per wave (a high-resolution pass has mostly such bins: config 4 averages 65 keys
+    // nor a barrier, and go one PER WAVE to a unit (a high-resolution pass has mostly such bins: config 4 averages 65 keys
     // per non-empty tile, and three of the four waves of a one-bin workgroup did nothing).
     constexpr int kClass63 = (kBuckets - 2) - 5, kClass1 = kBuckets - 2;       // classes of n in [32, 63] and of n == 1
     uint32_t n_big = 0, n_small = 0;
@@ -998,10 +1099,10 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
         if (k < kClass63) n_big += f;
         else if (k < kClass1) n_small += f;
     }
-    const uint32_t n_units = n_big + ((n_small + 3u) >> 2);
+    const uint32_t n_units = n_big + ((n_small + kWaves - 1u) / kWaves);
     for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         if (unit >= n_big) {
-            const uint32_t item = n_big + 4u * (unit - n_big) + (uint32_t)wave;     // wave-uniform
+            const uint32_t item = n_big + (uint32_t)kWaves * (unit - n_big) + (uint32_t)wave;     // wave-uniform
             if (item < n_big + n_small) {
                 const uint4 it = kp.items[item];
                 const uint32_t n = it.z;
@@ -1013,44 +1114,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_tiles(const KP kp)
             continue;
         }
         const uint4 it = kp.items[unit];
-        const int v = (int)(it.x >> 20);
-        const uint32_t off = it.y, n = it.z;
-        unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-        if (n <= (uint32_t)kRankSortMax) {
-            // Runs of 64 keys are sorted inside a wave's registers (no LDS, no barrier); a key's final position is its
-            // position in its own run plus, for every other run, the number of keys smaller than it (keys are unique: the
-            // Gaussian index is the low word).  One barrier per tile, 7 dependent LDS reads per (key, other run).
-            constexpr int kPer = kRankSortMax / kBlock;             // keys per thread
-            const uint32_t runs = (n + 63u) >> 6;
-            unsigned long long mine[kPer];
-#pragma unroll
-            for (int e = 0; e < kPer; e++) {
-                const uint32_t i = (uint32_t)tid + e * kBlock;     // run (wave + 4 e), position lane
-                if ((uint32_t)(wave + 4 * e) < runs) {             // wave-uniform
-                    mine[e] = i < n ? keys[i] : ~0ull;             // the last run is padded with +inf
-                    wave_sort64(mine[e], lane);
-                    s_keys[i] = mine[e];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < kPer; e++) {
-                const uint32_t own = (uint32_t)(wave + 4 * e);
-                if (own < runs) {
-                    uint32_t rank = (uint32_t)lane;
-#pragma unroll
-                    for (uint32_t r = 0; r < (uint32_t)(kRankSortMax / 64); r++)      // unrolled: the searches overlap
-                        if (r < runs && r != own) rank += run_lower_bound(s_keys + ((r & 3u) * 64u + (r >> 2) * kBlock), mine[e]);
-                    if (mine[e] != ~0ull) keys[rank] = mine[e];
-                }
-            }
-        } else if (n <= (uint32_t)kSortLdsCap) {
-            sort_chunk_lds<kBlock, kSortLdsCap>(keys, n, s_keys, tid, wave, lane);
-        } else if (!kp.long_bins_elsewhere) {
-            // only when the host said that no such bin exists (T4D_FLAG_NO_LONG_BINS) and one appeared nevertheless:
-            // correct, but one 256-thread workgroup per bin - k_sort_long is the fast path
-            sort_bin_chunked<kBlock, kSortLdsCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
-        }
+        sort_one_bin<false, BLOCK>(kp, (int)(it.x >> 20), it.y, it.z, s_keys, tid, wave, lane);
         __syncthreads();                                           // s_keys is reused by the next item
     }
 }
@@ -1188,7 +1252,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
 // counted loops: almost no scalar-unit work per splat (the CU's single scalar unit is what bounded the first version
 // of these kernels).
 template <int NCHUNK, bool REVERSE, int SCALE>
-__device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NCHUNK], unsigned short *list, const int lane)
+__device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NCHUNK], unsigned short *list, const int lane,
+                                                const int chunk0 = 0)      // chunk0: staged slot of m[0]'s first bit, in chunks of 64
 {
     int cnt = 0;
 #pragma unroll
@@ -1199,7 +1264,7 @@ __device__ __forceinline__ int build_visit_list(const unsigned long long (&m)[NC
         const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
         const int tot = __builtin_popcountll(mw);
         // the mask is wave-uniform: it becomes the exec mask of the store as it is (a per-lane bit test cost three instructions)
-        if (__builtin_amdgcn_inverse_ballot_w64(mw)) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)(((c << 6) + lane) * SCALE);
+        if (__builtin_amdgcn_inverse_ballot_w64(mw)) list[cnt + (REVERSE ? tot - 1 - below : below)] = (unsigned short)((((c + chunk0) << 6) + lane) * SCALE);
         cnt += tot;
     }
     return cnt;
@@ -1275,20 +1340,26 @@ __device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t
 // (no same-splat conflicts to serialise).  Per-pixel arithmetic and its order are IDENTICAL in both builds: forward
 // outputs are bit-equal; the backward's partial sums are added up in a different (still fixed) order.
 #define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_FWD_WAVES, LAT ? 2 : T4D_FWD_WAVES)))
-template <bool LAT>
+// FB: splats staged per batch.  SEG: the launch is small enough for the segmented backward (kSeg): visit lists are built and
+// walked per kSeg list positions, and the blend state at every such boundary is kept for the backward (write_snapshot).
+template <bool LAT, int FB, bool SEG>
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
     constexpr int kU = LAT ? 8 : 4;                  // steps per group
     // splats staged per batch: the latency build has the LDS of a whole CU and lives as long as its longest tile - fewer batches
-    constexpr int kFB = LAT ? kBlock : kFwdBatch;
+    constexpr int kFB = FB;
     constexpr int kNull = kFB;                 // staged slot that can never contribute (opacity 0)
-    constexpr int kChunks = kFB / 64;
-    constexpr int kListStride = kFB + 8;       // u16 entries per row list (multiple of 4: 8-byte aligned rows)
+    constexpr int kSub = SEG ? kSeg : kFB;           // list positions per visit-list round
+    constexpr int kSubChunks = kSub / 64, kNSub = kFB / kSub;
+    constexpr int kListStride = kSub + 8;      // u16 entries per row list (multiple of 4: 8-byte aligned rows)
     constexpr int kRec = 48;                         // bytes per staged splat: xy, cut-off r2 (12, +4 pad) | scaled conic + opacity | rgb + depth
-    static_assert(kFB <= kBlock && kFB % 64 == 0, "one staging thread per slot (it clears the slot when the list is shorter)");
+    static_assert(kFB <= kBlock && kFB % 64 == 0 && kFB % kSub == 0, "one staging thread per slot (it clears the slot when the list is shorter)");
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFB + 1) * kRec];
     __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
     __shared__ uint32_t s_wave_done[4];
+    // latency build: the workgroup sorts its own tile's bin first (one launch and one trip through memory less than
+    // k_sort_tiles -> k_render_fwd) and stages from the sorted keys it still holds
+    __shared__ unsigned long long s_sort[LAT ? kSortLdsCap : 1];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
     // fill workgroups are spread evenly over the launch: workgroup b is one iff floor(b F / total) steps up at b
@@ -1310,6 +1381,10 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
     const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
+    // segmented backward: this tile's snapshot slots (a tile of one segment keeps none: its replay starts at the list's end)
+    float *snap = nullptr;
+    if (SEG && n > (uint32_t)kSeg)
+        snap = kp.snap + ((size_t)v * kp.slots_per_view + off / kSeg + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
 
     int px, py;
     tile_pixel(tid, tx, ty, px, py);
@@ -1327,13 +1402,52 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
+    // ---- latency build: sort, then keep one batch of records and two batches of keys in flight ----
+    // A lone workgroup per CU lives through every memory round trip of its tile: as the kernel was written a batch began with
+    // key -> (centre, conic, colour), two dependent trips while all four waves waited.  Here the records of batch b + 1 are
+    // requested before the walk of batch b and the keys of batch b + 2 with them; only the first batch waits.
+    bool keys_lds = false;
+    unsigned long long k_cur = ~0ull, k_nxt = ~0ull;
+    float2 pre_p = make_float2(0.f, 0.f);
+    float4 pre_c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pre_r0 = 0.f, pre_r1 = 0.f, pre_r2 = 0.f;
+    if (LAT) {
+        static_assert(!LAT || kFB == kBlock, "the latency build stages one splat per thread");
+        if (kp.fused_sort) {
+            sort_one_bin<true, kBlock>(kp, v, off, n, s_sort, tid, wave, lane);
+            __threadfence_block();
+            __syncthreads();
+            keys_lds = n <= (uint32_t)kSortLdsCap;
+        }
+        if ((uint32_t)tid < n) k_cur = keys_lds ? s_sort[tid] : keys[tid];
+        if ((uint32_t)(kFB + tid) < n) k_nxt = keys_lds ? s_sort[kFB + tid] : keys[kFB + tid];
+        const uint32_t g0 = (uint32_t)k_cur;
+        if (g0 < (uint32_t)kp.P) {
+            pre_p = xy[g0]; pre_c = co[g0];
+            pre_r0 = rgb[3 * (size_t)g0]; pre_r1 = rgb[3 * (size_t)g0 + 1]; pre_r2 = rgb[3 * (size_t)g0 + 2];
+        }
+    }
+
     for (uint32_t b = 0; b < n; b += kFB) {
         if (b != 0) {                                // a further batch: needed only while some pixel of the tile is unfinished
             if (lane == 0) s_wave_done[wave] = done_m == ~0ull ? 1u : 0u;
             __syncthreads();                         // (also: everyone has left the previous batch's records)
             if ((s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) != 0u) break;
         }
-        if (kFB == kBlock || tid < kFB) {
+        if (LAT) {
+            float4 head = make_float4(0.f, 0.f, -1.f, 0.f);      // (x, y, cut-off r2, -): a slot without a splat touches nothing
+            if (b + tid < n) {
+                // (g >= P: a stale entry of a truncated list - lazy mode after an arena overflow - is ignored)
+                if ((uint32_t)k_cur < (uint32_t)kp.P) {
+                    unsigned char *rec = s_rec + tid * kRec;
+                    head = make_float4(pre_p.x, pre_p.y, cutoff_radius2(pre_c), 0.f);
+                    *reinterpret_cast<float4 *>(rec + 16) = scale_conic(pre_c);
+                    *reinterpret_cast<float4 *>(rec + 32) = make_float4(pre_r0, pre_r1, pre_r2, __uint_as_float((uint32_t)(k_cur >> 32)));
+                }
+                r2_out[b + tid] = head.z;                // the backward stages the same splats: it reads the cut-off back
+            }
+            *reinterpret_cast<float4 *>(s_rec + tid * kRec) = head;
+        } else if (kFB == kBlock || tid < kFB) {
             float4 head = make_float4(0.f, 0.f, -1.f, 0.f);      // (x, y, cut-off r2, -): a slot without a splat touches nothing
             if (b + tid < n) {
                 const unsigned long long key = keys[b + tid];
@@ -1354,14 +1468,34 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             *reinterpret_cast<float4 *>(s_rec + tid * kRec) = head;
         }
         __syncthreads();
+        if (LAT) {
+            // the next batch's records and the keys of the one after it: in flight during this batch's walk.  Requested BEHIND the
+            // barrier (a barrier waits for every outstanding memory operation of the wave), by every thread, finished wave or not.
+            k_cur = k_nxt;
+            k_nxt = ~0ull;
+            const uint32_t pos2 = b + 2u * kFB + (uint32_t)tid;
+            if (pos2 < n) k_nxt = keys_lds ? s_sort[pos2] : keys[pos2];
+            const uint32_t g1 = (uint32_t)k_cur;
+            if (g1 < (uint32_t)kp.P) {
+                pre_p = xy[g1]; pre_c = co[g1];
+                pre_r0 = rgb[3 * (size_t)g1]; pre_r1 = rgb[3 * (size_t)g1 + 1]; pre_r2 = rgb[3 * (size_t)g1 + 2];
+            }
+        }
         if (done_m == ~0ull) continue;               // wave-uniform; still takes part in the barriers above
+        if (b == 0 && wave == 0) T4D_COUNT_ADD(8, 1);
+        T4D_COUNT_ADD(9, 1);
+        uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
+#pragma clang loop unroll(disable)
+        for (int sub = 0; sub < kNSub; sub++) {      // (one round per batch unless SEG)
+        const uint32_t sub_lo = b + (uint32_t)(sub * kSub);
+        if (sub != 0 && !(sub_lo < n)) break;
         // which of the staged splats can touch which of this wave's four sub-blocks (= DPP rows)
-        unsigned long long m[4][kChunks];
+        unsigned long long m[4][kSubChunks];
 #pragma unroll
-        for (int c4 = 0; c4 < kChunks; c4++) {
+        for (int c4 = 0; c4 < kSubChunks; c4++) {
             unsigned long long mc[4] = { 0ull, 0ull, 0ull, 0ull };
-            if (b + ((uint32_t)c4 << 6) < n) {           // wave-uniform: short lists leave most chunks of a batch empty
-                const float4 head = *reinterpret_cast<const float4 *>(s_rec + ((c4 << 6) + lane) * kRec);
+            if (sub_lo + ((uint32_t)c4 << 6) < n) {      // wave-uniform: short lists leave most chunks of a batch empty
+                const float4 head = *reinterpret_cast<const float4 *>(s_rec + (((sub * kSubChunks + c4) << 6) + lane) * kRec);
                 wave_touch_masks(make_float2(head.x, head.y), head.z, tx, ty, wave, mc);
             }
 #pragma unroll
@@ -1370,19 +1504,17 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         int nsteps = 0, cnts[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {                // one visit list per sub-block
-            cnts[r] = build_visit_list<kChunks, false, kRec>(m[r], s_list[wave][r], lane);
+            cnts[r] = build_visit_list<kSubChunks, false, kRec>(m[r], s_list[wave][r], lane, sub * kSubChunks);
             nsteps = max(nsteps, cnts[r]);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) pad_visit_list<kU>(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kRec));
         __builtin_amdgcn_wave_barrier();
         const unsigned short *list = s_list[wave][row];
-        T4D_COUNT_ADD(9, 1); T4D_COUNT_ADD(11, cnts[0] + cnts[1] + cnts[2] + cnts[3]);
-        if (b == 0 && wave == 0) T4D_COUNT_ADD(8, 1);
+        T4D_COUNT_ADD(11, cnts[0] + cnts[1] + cnts[2] + cnts[3]);
 #if T4D_ABL == 5
         nsteps = 0;
 #endif
-        uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
         for (int k = 0; k < nsteps; k += kU) {
             uint32_t e[kU];
 #pragma unroll
@@ -1426,7 +1558,21 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             T4D_COUNT_ADD(10, kU);
             if (done_m == ~0ull) break;
         }
+        if (SEG) {
+            // the blend state in front of list position sub_lo + kSeg, for the backward segment that ends there.  A pixel that is
+            // finished keeps its final state, which the backward takes from the final snapshot: a finished WAVE writes nothing.
+            if (done_m == ~0ull) break;
+            if (snap != nullptr && sub_lo + (uint32_t)kSeg < n) {
+                float *sp = snap + (size_t)(sub_lo / kSeg) * (kSnapFloats * kBlock);
+                sp[0] = T; sp[kBlock] = C0; sp[2 * kBlock] = C1; sp[3 * kBlock] = C2; sp[4 * kBlock] = D;
+            }
+        }
+        }
         if (last_e != 0xffffffffu) last_contributor = b + ((last_e * 43691u) >> 21) + 1u;     // entry / 48 for entries < 2^17
+    }
+    if (SEG && snap != nullptr) {                     // the final state, in the tile's last slot
+        float *sp = snap + (size_t)((n - 1u) / kSeg) * (kSnapFloats * kBlock);
+        sp[0] = T; sp[kBlock] = C0; sp[2 * kBlock] = C1; sp[3 * kBlock] = C2; sp[4 * kBlock] = D;
     }
     if (inside) {
         const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
@@ -1549,7 +1695,8 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #ifndef T4D_BWD_WAVES
 #define T4D_BWD_WAVES 5                  // = workgroups per CU (30.8 KB of LDS each); 4 is 14 % slower, 6 spills (round-3 sweep)
 #endif
-#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_BWD_WAVES, LAT ? 2 : T4D_BWD_WAVES)))
+// (the segmented build of small launches never has five workgroups per CU to place: four waves per SIMD, 128 registers, no spills)
+#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (SEG ? 4 : T4D_BWD_WAVES), LAT ? 2 : (SEG ? 4 : T4D_BWD_WAVES))))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
 constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the empty-tile share of cotangent_dot
 #ifdef T4D_TIMING      // experiment builds only (tools/ab_build.sh timing -DT4D_TIMING): s_memtime stamps of workgroup 0's phases
@@ -1562,9 +1709,12 @@ __device__ unsigned long long g_timing[512];
 // is all such a launch has anyway), so two rows holding the same splat in the same step never meet and the conflict
 // detection and its branches disappear; the gradient arithmetic is predicated with selects instead of an exec-masked region,
 // which lets the compiler interleave the four steps of a group.
-template <bool DA, bool LAT>
+// SEG: the segmented backward of small launches (kSeg): a work item is ONE segment of a tile list - workgroup b takes slot b of
+// the slot table - and the replay starts from the forward's snapshot at the segment's far end instead of from the list's end.
+template <bool DA, bool LAT, bool SEG>
 __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
+    static_assert(!SEG || kSeg == kBwdBatch, "one staged batch per segment");
     constexpr int kSlabs = LAT ? 16 : 4;
     constexpr int kChunks = (kBwdBatch + 63) / 64;
     constexpr int kListStride = kBwdBatch + 4;
@@ -1632,9 +1782,15 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         }
         return;
     }
+    uint4 it;
+    if (SEG) {
+        it = kp.slot_tab[blockIdx.x];                // one slot per workgroup; most slots hold no segment
+        if (it.w == 0u) return;
+    }
     for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
-    for (uint32_t item = blockIdx.x; item < (uint32_t)(kp.V * kp.T); item += kp.tile_blocks) {
-    const uint4 it = kp.items[item];
+    for (uint32_t item = blockIdx.x; item < (SEG ? blockIdx.x + 1u : (uint32_t)(kp.V * kp.T)); item += kp.tile_blocks) {
+    if (!SEG) it = kp.items[item];
+    const int seg_j = SEG ? (int)(it.w & 0x7fffffffu) : 0;           // this item's segment: list positions [seg_j kSeg, (seg_j + 1) kSeg)
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
@@ -1681,6 +1837,24 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     // and dL/dalpha_i = (q_i - acc') T_i hold exactly - one multiply and one fused multiply-add less per step, and for a black
     // background (Topo4D: helpers.py setup_camera, bg = 0) the same bits as before.
     float acc = vr[35] * dp0 + vr[36] * dp1 + vr[37] * dp2;
+    const int nb = (int)((n + kBwdBatch - 1) / kBwdBatch);
+    if (SEG && seg_j + 1 < nb) {
+        // A segment that does not end at the list's end starts from the forward's snapshot at position p = (seg_j + 1) kSeg:
+        // T = the transmittance in front of p, acc = the colour behind p as the recursion would hold it there,
+        // ((C_final - C_prefix(p)) . dL/dC (+ depth and alpha terms) + T_final bg . dL/dC) / T(p).  A pixel whose last contributor
+        // lies before p has its final state at p: exactly the start values above (the forward writes no snapshot for a
+        // finished wave, so nothing is read for such a pixel).
+        const uint32_t p = (uint32_t)(seg_j + 1) * kSeg;
+        if (last_contributor > p) {
+            const float *sb = kp.snap + ((size_t)v * kp.slots_per_view + off / kSeg + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
+            const float *sp = sb + (size_t)seg_j * (kSnapFloats * kBlock), *sf = sb + (size_t)(nb - 1) * (kSnapFloats * kBlock);
+            const float Tp = sp[0];
+            float suf = fmaf(sf[kBlock] - sp[kBlock], dp0, fmaf(sf[2 * kBlock] - sp[2 * kBlock], dp1, (sf[3 * kBlock] - sp[3 * kBlock]) * dp2));
+            if (DA) suf = fmaf(sf[4 * kBlock] - sp[4 * kBlock], ddep, suf) + (Tp - T_final) * dalp;
+            acc = fmaf(T_final, acc, suf) / Tp;
+            T = Tp;
+        }
+    }
 
     const uint32_t rmax_v = row_max_u32(last_contributor);
     uint32_t row_max[4];
@@ -1691,12 +1865,11 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     __syncthreads();
     const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
-    const int nb = (int)((n + kBwdBatch - 1) / kBwdBatch);
     T4D_STAMP(1);
 #ifdef T4D_TIMING
     if (blockIdx.x == 0 && tid == 0) { g_timing[2] = n; g_timing[3] = tile_max; }
 #endif
-    for (int bi = nb - 1; bi >= 0; bi--) {
+    for (int bi = SEG ? seg_j : nb - 1; bi >= (SEG ? seg_j : 0); bi--) {
         const uint32_t lo = (uint32_t)bi * kBwdBatch;
         T4D_STAMP(8 + 8 * (nb - 1 - bi));
         const int cnt = (int)min((uint32_t)kBwdBatch, n - lo);
@@ -1938,7 +2111,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         }
         __syncthreads();
     }
-    if (kp.tile_dot) {
+    if (kp.tile_dot && seg_j == 0) {
         // The suffix recursion has reached the eye: acc = sum_i T_i alpha_i q_i + T_final bg . dL/dC = <colour, dL/dC> (+ <depth, dL/dD> +
         // <alpha, dL/dA>), this pixel's <outputs, cotangents> - the per-view sum costs one reduction per tile.
         // One float per wave, no barrier: a workgroup's lifetime is what this launch is made of.
@@ -2481,6 +2654,15 @@ bool latency_launch(int n_tiles)
     const char *e = getenv("T4D_LATENCY_TILES");        // read per call: the tests switch builds at run time
     return n_tiles <= (e ? atoi(e) : 4 * device_cus());
 }
+// The FORWARD's latency build (registers for instruction-level parallelism, its own tile's bin sorted in the workgroup, records
+// of the next batch in flight during the walk) stays ahead of the throughput build for much larger launches than the
+// backward's did (which needs 82 KiB of LDS per workgroup): T4D_FWD_LATENCY_TILES overrides, T4D_LATENCY_TILES too (tests).
+bool latency_launch_fwd(int n_tiles)
+{
+    const char *e = getenv("T4D_FWD_LATENCY_TILES");
+    if (!e) e = getenv("T4D_LATENCY_TILES");
+    return n_tiles <= (e ? atoi(e) : 12 * device_cus());
+}
 
 int check_problem(const T4DProblem *p)
 {
@@ -2537,6 +2719,9 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.sort_tmp = reinterpret_cast<unsigned long long *>(st + L.sort_tmp);
     kp.final_T = reinterpret_cast<float *>(st + L.final_T);
     kp.n_contrib = reinterpret_cast<uint32_t *>(st + L.n_contrib);
+    kp.slot_tab = reinterpret_cast<uint4 *>(st + L.slot_tab);
+    kp.snap = reinterpret_cast<float *>(st + L.snap);
+    kp.slots_per_view = seg_capable(p) ? (uint32_t)seg_slots_per_view(p, (size_t)kp.T) : 0u;
 }
 
 }  // namespace
@@ -2646,20 +2831,37 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         hipLaunchKernelGGL(k_scatter, dim3(gaussian_grid(p.P, p.n_views) + (unsigned)(((size_t)kp.T * p.n_views + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_scatter");
-    { ProfScope ps_(stream, K_SORT_TILES);
-    hipLaunchKernelGGL(k_sort_tiles, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
+    // Who sorts the bins.  A big launch: k_sort_tiles on 256 threads.  A small launch (at most kSegMaxTiles tiles) waits for its
+    // longest bin: 1024 threads per bin - unless the forward runs its latency build AND the caller knows that every bin fits the
+    // one-pass ranking sort (T4D_FLAG_SHORT_BINS): then the render workgroup of a tile sorts its own bin (no launch at all).
+    const bool lat = latency_launch_fwd(kp.T * p.n_views);
+    kp.fused_sort = (lat && (p.flags & T4D_FLAG_SHORT_BINS) != 0 && getenv("T4D_NO_FUSED_SORT") == nullptr) ? 1u : 0u;
+    if (!kp.fused_sort) {
+        ProfScope ps_(stream, K_SORT_TILES);
+        // (1024 threads per bin only pay when some bin is long: with the caller's word that every bin fits the ranking sort, a
+        // small launch of several views keeps the 256-thread kernel - 4 views of Topo4D's size: 9.7 against 12.6 us)
+        if (kp.slots_per_view != 0u && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
+            hipLaunchKernelGGL(k_sort_tiles<kLongBlock>, dim3(min(kp.T * p.n_views, 4 * device_cus())), dim3(kLongBlock), 0, stream, kp);
+        else
+            hipLaunchKernelGGL(k_sort_tiles<kBlock>, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
     }
     if (kp.long_bins_elsewhere)
         hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
-    const bool lat = latency_launch(kp.T * p.n_views);
     kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 6, 2));
     kp.fill_blocks = (uint32_t)(kp.gy * p.n_views);
     kp.fill_vec = (p.W % 4 == 0 && (((uintptr_t)io->out_color | (uintptr_t)io->out_depth | (uintptr_t)io->out_alpha) & 15u) == 0) ? 1u : 0u;
     if (getenv("T4D_FILL_SCALAR")) kp.fill_vec = 0u;       // tests: the 4-byte path on images that would take the 16-byte one
-    if (lat) hipLaunchKernelGGL(k_render_fwd<true>, dim3(kp.tile_blocks + kp.fill_blocks), dim3(kBlock), 0, stream, kp);
-    else hipLaunchKernelGGL(k_render_fwd<false>, dim3(kp.tile_blocks + kp.fill_blocks), dim3(kBlock), 0, stream, kp);
+    const dim3 fgrid(kp.tile_blocks + kp.fill_blocks);
+    const bool seg = kp.slots_per_view != 0u;        // small launch: snapshots for the segmented backward (kSeg)
+    if (lat) {
+        if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_fwd<true, kBlock, false>), fgrid, dim3(kBlock), 0, stream, kp);
+    } else {
+        if (seg) hipLaunchKernelGGL((k_render_fwd<false, kBlock, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, false>), fgrid, dim3(kBlock), 0, stream, kp);
+    }
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
     return T4D_OK;
@@ -2709,15 +2911,22 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     { ProfScope ps_(stream, K_RENDER_BWD);
     const bool da = kp.dL_ddepth || kp.dL_dalpha;
     const bool lat = latency_launch(kp.T * p.n_views);
-    kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 4, 2));
+    // small launches: one workgroup per segment slot (kSeg; T4D_NO_SEGMENTS=1: whole tiles, for tests and experiments - the
+    // forward's state serves both)
+    const bool seg = kp.slots_per_view != 0u && getenv("T4D_NO_SEGMENTS") == nullptr;
+    kp.tile_blocks = seg ? (uint32_t)p.n_views * kp.slots_per_view
+                         : (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 4, 2));
     const uint32_t grid = kp.tile_blocks + (kp.tile_dot ? (uint32_t)p.n_views * ((kp.T + kEmptySpan - 1) / kEmptySpan) : 0u);
-    if (lat) {
-        if (da) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_bwd<false, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
+#define T4D_BWD_LAUNCH(DA_, LAT_, SEG_) hipLaunchKernelGGL((k_render_bwd<DA_, LAT_, SEG_>), dim3(grid), dim3(kBlock), 0, stream, kp)
+    if (seg) {
+        // Segments always run the throughput build: the latency build's one slab per DPP row is 82 KiB of LDS, ONE workgroup per
+        // CU, and a one-view launch has more segments than CUs (432 at Topo4D's size: two rounds, 47 us against 29 us measured)
+        if (da) T4D_BWD_LAUNCH(true, false, true); else T4D_BWD_LAUNCH(false, false, true);
     } else {
-        if (da) hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(grid), dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_bwd<false, false>), dim3(grid), dim3(kBlock), 0, stream, kp);
+        if (lat) { if (da) T4D_BWD_LAUNCH(true, true, false); else T4D_BWD_LAUNCH(false, true, false); }
+        else { if (da) T4D_BWD_LAUNCH(true, false, false); else T4D_BWD_LAUNCH(false, false, false); }
     }
+#undef T4D_BWD_LAUNCH
     }
     T4D_LAUNCH_CHECK("k_render_bwd");
     { ProfScope ps_(stream, K_PREPROCESS_BWD);

@@ -387,6 +387,8 @@ class ViewBatch:
         longest = _LONGEST_BIN.get((self.device.index, P, self.H, self.W))
         if longest is not None and longest <= 1536:
             flags |= T4D_FLAG_NO_LONG_BINS
+            if longest <= 448:            # ... and below the one-pass ranking sort (512): small launches sort inside the render kernel
+                flags |= _lib.T4D_FLAG_SHORT_BINS
         return flags
 
     def _stream(self):
