@@ -403,12 +403,13 @@ def drop_in_probe(dev, reps=5):
                     fn(i)
                 torch.cuda.synchronize(dev)
                 runs.append(n / (time.perf_counter() - t0))
-            out[name] = round(max(runs), 1)
+            out[name] = round(sorted(runs)[len(runs) // 2], 1)
             out[name + "_runs"] = [round(x, 1) for x in runs]
     finally:
         rasterizer._restore_sync_mode(saved)
     out["note"] = ("host-bound: an iteration is the reference's own torch ops (params2rendervar forward + autograd backward, "
-                   "params2rendervar_only_it_per_s) plus the drop-in call (it_per_s_without_params2rendervar); best of the listed runs; "
+                   "params2rendervar_only_it_per_s) plus the drop-in call (it_per_s_without_params2rendervar); MEDIAN of the listed runs "
+                   "(the loop has two regimes - the host just ahead of the GPU or just behind it - and a run can sit in either); "
                    "GPU time per view is single_view.gpu_us_per_view")
     return out
 

@@ -48,8 +48,9 @@
 
 namespace {
 
-// T4D_ABL (ablation builds, tools/ablate.sh; never defined in the shipped library):
-//   1 = backward: skip the cross-lane reduction + LDS slab write      2 = backward: skip the gradient arithmetic too
+// T4D_ABL (ablation builds, tools/ablate.sh; never defined in the shipped library) - whole phases only, nothing inside the step
+// bodies of the render kernels (the in-step ablations and the s_memtime stamps of rounds 2-3 are recorded, with their numbers, in
+// tools/experiments/README.md):
 //   3 = backward: skip the whole visit loop (staging + write-out only) 4 = forward: skip blending (alpha evaluation only)
 //   5 = forward: skip the whole visit loop      6 / 7 = preprocess: stop before / after the pair-slot allocation
 #ifndef T4D_ABL
@@ -620,9 +621,9 @@ __device__ __forceinline__ int count_bucket(const uint32_t c)
 }
 
 // Per-tile kernels walk the length-ordered tile list with a grid-stride loop (grid size: tile_grid() on the host; a
-// fully resident grid was measured slower than the hardware dispatcher's dynamic balancing and is only kept behind
-// T4D_PERSISTENT=1).  Heavy tiles start first and consecutive heavy tiles land on different XCDs (block b runs on XCD
-// b % 8); empty tiles sit at the end of the list and end the loop.
+// fully resident grid was measured slower than the hardware dispatcher's dynamic balancing: tools/experiments/README.md).
+// Heavy tiles start first and consecutive heavy tiles land on different XCDs (block b runs on XCD b % 8); empty tiles sit at
+// the end of the list and end the loop.
 struct TileOrder {
     uint32_t pre[kBuckets + 1];     // exclusive prefix of the bucket totals (wave-uniform, lives in SGPRs)
 };
@@ -1399,6 +1400,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     const float bg1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(vr[36])));
     const float bg2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(vr[37])));
     unsigned long long done_m = __ballot(!inside);   // pixels that take no more splats, as a wave mask
+    uint32_t gate = inside ? 0xffffffffu : 0u;       // (latency build: the same per lane, all ones while the pixel takes splats)
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last_contributor = 0;
 
@@ -1531,13 +1533,43 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 if (LAT) cds[u] = *reinterpret_cast<const float4 *>(s_rec + e[u] + 32);      // every LDS read of the group up front
                 float p2, G;
                 eval_splat(*reinterpret_cast<const float4 *>(s_rec + e[u] + 16), g_xy - pix_f, p2, G, alpha[u]);
-                valid[u] = __ballot(!(p2 > 0.0f)) & __ballot(!(alpha[u] < T4D_ALPHA_MIN));
+                if (LAT) {                               // the two rejections fold into alpha itself (see the blend below)
+                    const float a1 = p2 > 0.0f ? 0.f : alpha[u];
+                    alpha[u] = a1 < T4D_ALPHA_MIN ? 0.f : a1;
+                } else {
+                    valid[u] = __ballot(!(p2 > 0.0f)) & __ballot(!(alpha[u] < T4D_ALPHA_MIN));
+                }
             }
 #if T4D_ABL == 4
             if (alpha[0] + alpha[1] + alpha[2] + alpha[3] == 12345.f) C0 += 1.f;
             continue;
 #endif
             // (no "does any lane blend?" test: with four different splats in flight per step the answer is almost always yes)
+            if (LAT) {
+                // The latency build's blend: ONE wave per SIMD walks a dependent chain, so what counts is the LENGTH of the chain from
+                // one splat's transmittance to the next, not the instruction count.  With wave masks that chain crosses from the
+                // vector to the scalar unit and back per splat (compare -> mask logic -> select: ~125 cycles per step measured);
+                // here it stays in the vector unit: a splat that must not blend - rejected, or its pixel finished (gate = 0) - takes
+                // part with alpha = 0, for which every update below is the identity (T * 1, C + c * 0), bit for bit what the
+                // throughput build's skipped update leaves.  (T >= T_STOP holds for every pixel that still takes splats, so a
+                // zero alpha can never raise `stop`.)
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const float a = __uint_as_float(__float_as_uint(alpha[u]) & gate);
+                    const float test_T = T * (1.f - a);
+                    const bool stop = test_T < T4D_T_STOP;
+                    const float w = stop ? 0.f : a * T;
+                    gate = stop ? 0u : gate;
+                    const float4 cd = cds[u];
+                    C0 = fmaf(cd.x, w, C0); C1 = fmaf(cd.y, w, C1); C2 = fmaf(cd.z, w, C2);
+                    D = fmaf(cd.w, w, D);
+                    T = stop ? T : test_T;
+                    last_e = w != 0.f ? e[u] : last_e;
+                }
+                done_m = __ballot(gate == 0u);
+                if (done_m == ~0ull) break;
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < kU; u++) {               // blending is sequential in list order
                 // Predicates as 64-bit wave masks combined with scalar instructions: written with bools, the compiler evaluates
@@ -1699,12 +1731,6 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (SEG ? 4 : T4D_BWD_WAVES), LAT ? 2 : (SEG ? 4 : T4D_BWD_WAVES))))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
 constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the empty-tile share of cotangent_dot
-#ifdef T4D_TIMING      // experiment builds only (tools/ab_build.sh timing -DT4D_TIMING): s_memtime stamps of workgroup 0's phases
-__device__ unsigned long long g_timing[512];
-#define T4D_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 512) g_timing[(i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define T4D_STAMP(i) do { } while (0)
-#endif
 // LAT: the latency build (see k_render_fwd): one slab per DPP ROW instead of one per wave (82 KB of LDS: one workgroup per CU
 // is all such a launch has anyway), so two rows holding the same splat in the same step never meet and the conflict
 // detection and its branches disappear; the gradient arithmetic is predicated with selects instead of an exec-masked region,
@@ -1794,10 +1820,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
-    T4D_STAMP(0);
-#ifdef T4D_TIMING
-    if (blockIdx.x == 0 && tid == 0) g_timing[5] = wall_clock64();
-#endif
     if (n == 0) break;                                             // ordered by length: only empty tiles remain
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float *r2_in = kp.cut_r2 + (size_t)v * kp.cap + off;
@@ -1865,13 +1887,8 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     __syncthreads();
     const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
 
-    T4D_STAMP(1);
-#ifdef T4D_TIMING
-    if (blockIdx.x == 0 && tid == 0) { g_timing[2] = n; g_timing[3] = tile_max; }
-#endif
     for (int bi = SEG ? seg_j : nb - 1; bi >= (SEG ? seg_j : 0); bi--) {
         const uint32_t lo = (uint32_t)bi * kBwdBatch;
-        T4D_STAMP(8 + 8 * (nb - 1 - bi));
         const int cnt = (int)min((uint32_t)kBwdBatch, n - lo);
         const bool live = lo < tile_max;      // workgroup-uniform
         // ---- stage ----
@@ -1914,7 +1931,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             }
         }
         __syncthreads();
-        T4D_STAMP(9 + 8 * (nb - 1 - bi));
         if (live) {
             // which of the staged splats can touch which of this wave's four sub-blocks: the forward's test, on the forward's numbers
             unsigned long long mt[4][kChunks];
@@ -1983,10 +1999,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             // geometry records, and a step's slab value is read BEFORE its arithmetic and written back after it
             // (same wave, program order: the previous step's write is already ahead of the read in the LDS queue).
             uint2 pk = *reinterpret_cast<const uint2 *>(list);
-            T4D_STAMP(10 + 8 * (nb - 1 - bi));
-#ifdef T4D_TIMING
-            if (blockIdx.x == 0 && tid == 0 && 13 + 8 * (nb - 1 - bi) < 512) g_timing[13 + 8 * (nb - 1 - bi)] = nsteps;
-#endif
             for (int k = 0; k < nsteps; k += 4) {
                 const uint32_t ee[4] = { pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16 };
                 pk = *reinterpret_cast<const uint2 *>(list + k + 4);          // the lists are padded: always readable
@@ -2004,11 +2016,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     eval_splat(make_float4(q01.x, q01.y, q23.x, q23.y), ds[u], p2, Gs[u], alphas[u]);
                     contribs[u] = (int)ee[u] < lc_rel && !(p2 > 0.0f) && !(alphas[u] < T4D_ALPHA_MIN);
                 }
-#if T4D_ABL == 40            // timing experiment: no step is treated as a same-splat conflict (wrong sums)
-                const uint32_t cbits = 0u;
-#else
                 const uint32_t cbits = (uint32_t)(conflict_s[kChunks == 1 ? 0 : (k >> 6)] >> (k & 63));
-#endif
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
@@ -2020,10 +2028,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     float *dst = reinterpret_cast<float *>(slab + (LAT ? (ee[u] & slab_and) : ee[u]));
                     const float old = *dst;              // early read of the slab value this step adds to
                     float e = 0.f, w = 0.f;
-#if T4D_ABL == 2
-                    if (contrib) e = alpha + G + d.x + d.y;
-                    if (false) {
-#else
                     if (LAT) {
                         // the same operations in the same order as the exec-masked region below, on every lane; the selects keep
                         // the state of the lanes that do not contribute
@@ -2040,13 +2044,17 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         e = contrib ? G * dL_dalpha : 0.f;
                         acc = contrib ? fmaf(alpha, qma, acc) : acc;
                     } else if (contrib) {
-#endif
                         // Per lane only what depends on the pixel: e = G * dL/dalpha and its first/second moments about
                         // the splat centre, and w * dL/dC.  Everything that is constant per splat (opacity, conic,
                         // 0.5*W, -0.5 ...) is applied ONCE per Gaussian after all tiles are summed (k_preprocess_bwd).
                         const float4 cd = cds[u];
                         const float om = 1.f - alpha;                              // >= 0.01
+#ifdef T4D_RCP_NEWTON     // experiment (tools/ab_build.sh newton -DT4D_RCP_NEWTON): 1 / (1 - alpha) to within half an ulp; see DESIGN.md section 2
+                        const float inv0 = __builtin_amdgcn_rcpf(om);
+                        const float inv = fmaf(fmaf(-om, inv0, 1.f), inv0, inv0);
+#else
                         const float inv = __builtin_amdgcn_rcpf(om);
+#endif
                         T = T * inv;
                         w = alpha * T;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));
@@ -2062,9 +2070,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                     // lanes that do not contribute carry e = w = 0, so their ten products are exact zeros
                     const v2f ed = e * d, edd = ed * d, wdp = w * dp01;
                     float r[10] = { e, ed.x, ed.y, edd.x, ed.x * d.y, edd.y, wdp.x, wdp.y, w * dp2, DA ? w * ddep : 0.f };
-#if T4D_ABL == 1 || T4D_ABL == 2
-                    if (r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] + r[9] + old == 12345.f) s_acc[wave][0][0] = r[0];
-#else
                     const float tot = reduce10_row<!DA>(r);
                     // Plain read-add-write into the wave's slab (ds_add_f32 retires ~3 cycles per LANE on this part).  Idle
                     // rows add their zeros to the null splat's row, which nobody reads.
@@ -2081,13 +2086,10 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                             __builtin_amdgcn_wave_barrier();
                         }
                     }
-#endif
                 }
             }
         }
-        T4D_STAMP(11 + 8 * (nb - 1 - bi));
         __syncthreads();
-        T4D_STAMP(12 + 8 * (nb - 1 - bi));
         // ---- write one record per pair (zeros when no wave touched it); fixed wave order => deterministic ----
         if (tid < cnt) {
             float a[10];
@@ -2118,10 +2120,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         const float d = wave_sum_to_lane63(acc);
         if (lane == 63) kp.tile_dot[((size_t)v * kp.T + t_) * 4 + wave] = d;
     }
-    T4D_STAMP(4);
-#ifdef T4D_TIMING
-    if (blockIdx.x == 0 && tid == 0) g_timing[6] = wall_clock64();
-#endif
     }
 }
 
@@ -2626,20 +2624,17 @@ int device_cus()
 }
 
 // Grid of the per-tile kernels.  They are grid-stride loops over the length-ordered work items, so the grid size is a
-// free choice.  Measured on MI355X (config 2): a RESIDENT grid (CUs x 4-6 workgroups, T4D_PERSISTENT=1) loses 1.3x to
+// free choice.  Measured on MI355X (config 2): a RESIDENT grid (CUs x 4-6 workgroups; the switch is gone) loses 1.3x to
 // the hardware dispatcher's dynamic balancing; one workgroup per tile pays ~25k workgroup launches of which two
 // thirds only find an empty tile; V*T / div workgroups, each taking items b, b+G, b+2G, ... (one from every length
 // class, heavy first), keeps the dynamic balancing and divides the launch overhead.  T4D_TILE_DIV overrides div.
 int tile_grid(int n_tiles, int per_cu, int div)
 {
-    static int persistent = -1, env_div = -1;
-    if (persistent < 0) {
-        const char *e = getenv("T4D_PERSISTENT");
-        persistent = (e && e[0] == '1') ? 1 : 0;
+    static int env_div = -1;
+    if (env_div < 0) {
         const char *d = getenv("T4D_TILE_DIV");
         env_div = d ? atoi(d) : 0;
     }
-    if (persistent) return min(n_tiles, device_cus() * per_cu);
     if (env_div > 0) return max(min(n_tiles, device_cus() * per_cu), (n_tiles + env_div - 1) / env_div);
     // ... up to kMaxGridPerCu workgroups per CU: beyond that (config 4: 393k tiles per launch) more workgroups only add prologues -
     // the best div measured there was 12-16 (24-33k workgroups: 5.13 -> 4.79 ms per step), at config 2 (24.6k tiles) it is 2
@@ -2959,12 +2954,6 @@ T4D_EXPORT int t4d_debug_read_counters(unsigned long long *out, int reset)
 }
 #endif
 
-#ifdef T4D_TIMING
-T4D_EXPORT int t4d_debug_read_timing(unsigned long long *out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timing), sizeof(unsigned long long) * (size_t)min(n, 512));
-}
-#endif
 
 T4D_EXPORT int t4d_profile_begin(void)
 {

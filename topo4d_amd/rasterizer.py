@@ -526,14 +526,6 @@ class ViewBatch:
         if self.inputs is None:
             raise RuntimeError("this ViewBatch's inputs are owned by an autograd graph (GaussianRasterizer / rasterize_views): "
                                "call .backward() on the loss instead of ViewBatch.backward()")
-        pending = self.pending
-        if pending is not None:
-            # "auto" mode: no gradient of a truncated render ever leaves this function (the status was copied out right behind
-            # the forward's binning kernels: normally two host loads, see poll_truncation)
-            if not pending.done:
-                poll_truncation(wait_for=pending)
-            if pending.overflow:
-                raise _truncation_error((pending.need, pending.cap))
         dev = self.device
         means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs = self.inputs
         V, P, H, W = self.V, int(means3D.shape[0]), self.H, self.W
@@ -572,6 +564,15 @@ class ViewBatch:
         io.dL_dcolors = _dp(g["colors_precomp"]); io.dL_dshs = _dp(g["shs"]); io.dL_dopacities = g["opacities"].data_ptr()
         io.dL_dscales = _dp(g["scales"]); io.dL_drotations = _dp(g["rotations"]); io.dL_dcov3D = _dp(g["cov3D_precomp"])
         io.scratch = scratch.data_ptr(); io.scratch_bytes = sbytes; io.cotangent_dot = _dp(cotangent_dot)
+        pending = self.pending
+        if pending is not None:
+            # "auto" mode: no gradient of a truncated render ever leaves this function.  The status was copied out right behind
+            # the forward's binning kernels and is looked at HERE, after the host-side preparation above: normally two host
+            # loads (see poll_truncation); a host that runs ahead of the GPU waits for those two words, not for the stream
+            if not pending.done:
+                poll_truncation(wait_for=pending)
+            if pending.overflow:
+                raise _truncation_error((pending.need, pending.cap))
         rc = lib.t4d_rasterize_backward(C.byref(prob), plan.bio_ref, _raw_stream(dev))
         if rc != T4D_OK:
             raise RuntimeError(f"t4d_rasterize_backward failed (code {rc}): {_lib.last_error()}")
