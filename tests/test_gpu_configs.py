@@ -320,25 +320,32 @@ def test_soak_seed_962_flipped_pixel_beyond_the_absolute_bound(render_build):
         _randomised_trial(962, strict=True)
 
 
-def test_randomised_soak_both_builds(monkeypatch):
-    """Time-boxed soak inside the suite: at least 50 further seeds under BOTH builds of the render kernels (more while the box
+BUILDS = (("throughput", {"T4D_LATENCY_TILES": "0", "T4D_NO_SEGMENTS": "1"}),          # what a 24-view launch runs
+          ("latency + segments", {"T4D_LATENCY_TILES": "1000000000"}),                 # what a one-view call runs
+          ("throughput + segments", {"T4D_LATENCY_TILES": "0"}))                       # what a 2-8 view launch runs
+
+
+def test_randomised_soak_all_builds(monkeypatch):
+    """Time-boxed soak inside the suite: at least 50 further seeds under EVERY build of the render kernels (more while the box
     has time left).  Round 2's soak of 400 runs (tools/soak_parity.py) had one scene miss the plain gradient tolerance because
     of ONE threshold pixel; with the flip-aware check every run must be green."""
     import time
     t0 = time.time()
     done = flips = 0
     for trial in range(12, 412):
-        for tiles in ("0", "1000000000"):                    # throughput build, latency build
-            monkeypatch.setenv("T4D_LATENCY_TILES", tiles)
+        for name, env in BUILDS:
+            monkeypatch.delenv("T4D_NO_SEGMENTS", raising=False)
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
             try:
                 flips += _randomised_trial(trial)
             except AssertionError as e:
-                raise AssertionError(f"trial {trial} (T4D_LATENCY_TILES={tiles}): {e}") from e
+                raise AssertionError(f"trial {trial} ({name}): {e}") from e
         done += 1
         if done >= 50 and time.time() - t0 > 150.0:
             break
     assert done >= 50
-    print(f"soak: {done} seeds x 2 builds, {flips} threshold pixels in total, {time.time() - t0:.0f} s")
+    print(f"soak: {done} seeds x {len(BUILDS)} builds, {flips} threshold pixels in total, {time.time() - t0:.0f} s")
 
 
 # ------------------------------------------------------------------------------------------------------------------

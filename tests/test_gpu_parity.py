@@ -43,7 +43,8 @@ def flipped_pixels(hip, v, r, n_contrib_mine):
     return np.argwhere(bad)
 
 
-FLIP_GRAD_REL = 5e-2
+FLIP_GRAD_REL = 2e-2          # a Gaussian with a flipped pixel in reach: at most this share of the tensor's largest entry ...
+FLIP_GRAD_ABS = 1e-3          # ... and never more than this (a large localised error must still fail; soaks saw <= 1.4e-4)
 
 
 def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_KEYS, rel=GRAD_REL, truth=None):
@@ -53,7 +54,7 @@ def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_K
     opacity 1, beyond the 3-sigma radius - where the flip moves that pixel's transmittance for every splat behind the flipped
     one and the "colour behind" for every splat in front of it.  Such a Gaussian's gradient differs by that pixel's whole
     contribution (soak seed 962: 1.4e-4 absolute, 0.25 % of the tensor's largest); it is held to FLIP_GRAD_REL of the tensor's
-    largest entry - a sanity bound, not a precision claim.
+    largest entry and FLIP_GRAD_ABS absolute - sanity bounds eight times the worst of 6,000 soak runs, not a precision claim.
     `truth` (optional): a callable returning the float64 autograd oracle's gradients of this view.  The C oracle computes in
     fp32 like the kernels and has rounding of its own (soak seed 2635: a cancelling scale gradient of a x8 anisotropic splat,
     C oracle 8e-8 from the float64 value, HIP 7e-9); a Gaussian without a flipped pixel in reach that misses the tolerance
@@ -80,7 +81,8 @@ def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_K
                 if np.abs(a[i] - t[i]).max() <= rel * scale + 1e-9:
                     continue                              # the fp32 reference is the one that is off here
             assert near.any(), f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} with no flipped pixel in reach"
-            assert err[i] <= FLIP_GRAD_REL * scale, f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} is more than one pixel's share"
+            assert err[i] <= min(FLIP_GRAD_REL * scale, FLIP_GRAD_ABS), \
+                f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} is more than one pixel's share"
 
 
 def check_n_contrib(mine, ref, max_flips=0):
@@ -567,37 +569,43 @@ def test_sh_backward_degree3_kernel_equals_the_general_one(monkeypatch):
 
 
 def test_one_view_scan_and_scatter_in_one_launch(monkeypatch):
-    """One view of at most 1,024 tiles (Topo4D's own call shape) runs k_scan_scatter_small instead of k_scan_tiles + k_scatter.
-    Everything the two kernels leave behind must be identical: tile offsets, the view's total, the status block, the sorted keys
+    """One view of at most 1,024 tiles (Topo4D's own call shape) runs its binning front end as ONE launch - k_front_small:
+    preprocess, then scan and scatter behind a grid-wide barrier - or, with T4D_NO_FRONT_FUSION, as k_preprocess ->
+    k_scan_scatter_small, instead of the three kernels of a multi-view launch (T4D_NO_SMALL_VIEW).
+    Everything the paths leave behind must be identical: tile offsets, the view's total, the status block, the sorted keys
     of every tile, the outputs and the gradients; the work items may come in another order inside a length class (both orders
     are arbitrary), so they are compared as sets per class.  Sizes: 512x375 with Topo4D's 8,280 Gaussians, a 1,024-tile
     image, and a tiny one."""
     from scaffold import scene
+    switches = ("T4D_NO_FRONT_FUSION", "T4D_NO_SMALL_VIEW")
     for (n_lat, n_lon, H, W) in ((69, 120, 512, 375), (40, 60, 512, 512), (6, 8, 33, 90)):
         rv, cams = util.make_scene(n_lat, n_lon, H, W, 24 if H > 100 else 3, opacity="A", seed=3)
         cams = cams[len(cams) // 2: len(cams) // 2 + 1]
         dc, _, _ = scene.output_cotangents(1, H, W, seed=4)
         res = []
-        for off in (False, True):
-            if off:
-                monkeypatch.setenv("T4D_NO_SMALL_VIEW", "1")
-            else:
-                monkeypatch.delenv("T4D_NO_SMALL_VIEW", raising=False)
+        for env in ({}, {"T4D_NO_FRONT_FUSION": "1"}, {"T4D_NO_SMALL_VIEW": "1"}):
+            for k in switches:
+                monkeypatch.delenv(k, raising=False)
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
             hip, hg, batch = util.hip_render(cams, rv, dc)
             st = util.decode_state(batch)
             res.append((hip, hg, st, batch.last_status))
-        monkeypatch.delenv("T4D_NO_SMALL_VIEW", raising=False)
-        (h0, g0, s0, t0), (h1, g1, s1, t1) = res
-        assert (t0.max_pairs_per_view, t0.total_pairs, t0.overflow, t0.max_tile_pairs) == \
-               (t1.max_pairs_per_view, t1.total_pairs, t1.overflow, t1.max_tile_pairs)
-        for k in ("tile_count", "tile_off", "view_total", "bucket_fill"):
-            assert np.array_equal(s0[k], s1[k]), k
-        tc, to = s0["tile_count"][0], s0["tile_off"][0]
-        for t in np.nonzero(tc)[0]:
-            assert np.array_equal(s0["keys"][0][to[t]:to[t] + tc[t]], s1["keys"][0][to[t]:to[t] + tc[t]]), int(t)
-        for k in ("color", "depth", "alpha", "radii"):
-            assert np.array_equal(h0[k], h1[k]), k
-        for k in util.GRAD_KEYS:
-            assert np.array_equal(g0[k], g1[k]), k
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        h1, g1, s1, t1 = res[2]
+        for h0, g0, s0, t0 in res[:2]:
+            assert (t0.max_pairs_per_view, t0.total_pairs, t0.overflow, t0.max_tile_pairs) == \
+                   (t1.max_pairs_per_view, t1.total_pairs, t1.overflow, t1.max_tile_pairs)
+            for k in ("tile_count", "tile_off", "view_total", "bucket_fill"):
+                assert np.array_equal(s0[k], s1[k]), k
+            tc, to = s0["tile_count"][0], s0["tile_off"][0]
+            for t in np.nonzero(tc)[0]:
+                assert np.array_equal(s0["keys"][0][to[t]:to[t] + tc[t]], s1["keys"][0][to[t]:to[t] + tc[t]]), int(t)
+            for k in ("color", "depth", "alpha", "radii"):
+                assert np.array_equal(h0[k], h1[k]), k
+            for k in util.GRAD_KEYS:
+                assert np.array_equal(g0[k], g1[k]), k
+        h0 = res[0][0]
         r, g = util.c_oracle_render(cams[0], rv, dc[0])
         check_outputs(h0, r.color, r.depth, r.alpha, 0, max_flips=2)

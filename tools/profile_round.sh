@@ -21,6 +21,8 @@ python tools/merge_counters.py gpurun_out/${R}_dense DENSE_1M > /dev/null
 python tools/merge_counters.py gpurun_out/${R}_single_view SINGLE_VIEW > /dev/null
 cp profiles/traffic.json profiles/valu.json profiles/lanes.json gpurun_out/ 2>/dev/null
 tools/side_benches.sh ${R}_side > /dev/null 2>&1
+python tools/small_launch.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_small_launch.txt      # 1-8 views per call, every build switch
+tools/micro/sort_bin > gpurun_out/${R}_sort_bin_micro.txt 2>&1
 python bench.py > gpurun_out/${R}_bench_c2.json 2> gpurun_out/${R}_bench_c2.err
 python bench.py --config C4 --steps 20 > gpurun_out/${R}_bench_c4.json 2> gpurun_out/${R}_bench_c4.err
 ls gpurun_out | grep ${R}_

@@ -110,6 +110,7 @@ struct DevStatus {            // first bytes of the state buffer
     uint32_t max_pairs;
     unsigned long long total_pairs;       // ... the 16 bytes T4D_FLAG_ASYNC_STATUS copies out end here
     uint32_t max_tile_pairs;              // longest tile list of the call (reported as T4DStatus.max_tile_pairs)
+    uint32_t grid_sync;                   // arrival counter of k_front_small's one grid-wide barrier
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -407,7 +408,15 @@ __host__ __device__ inline unsigned gaussian_grid(const int P, const int V) { re
 // ---------------------------------------------------------------------------------------------------------
 // A.1 preprocess (+ tile counting + pair-slot allocation)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
+// what a thread of the preprocess pass knows about its Gaussian afterwards (k_front_small goes on from here without re-reading it)
+struct PreOut {
+    uint32_t tiles, pbase;          // tiles touched; first pair slot (valid when fits)
+    int x0, y0, x1, y1;             // tile rectangle
+    float depth;
+    bool fits;
+};
+
+__device__ __forceinline__ void preprocess_body(const KP &kp, const uint32_t gb, const uint32_t vb, PreOut &po)
 {
 #pragma clang fp contract(off)
     __shared__ uint32_t s_wave_tot[4];
@@ -415,16 +424,9 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     __shared__ int s_bb[4];
     __shared__ uint32_t s_hist[kHist], s_hbase[kHist];
     const int tid = threadIdx.x;
-    const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
-    uint32_t gb, vb;
-#if T4D_GB_ORDER & 1
-    if (!block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, gb, vb)) return;          // padding of the last group of eight
-#else
-    vb = blockIdx.x / nblocks; gb = blockIdx.x - vb * nblocks;
-    if (vb >= (uint32_t)kp.V) return;
-#endif
     const int g = (int)gb * kBlock + tid;
     const int v = (int)vb;
+    po.tiles = 0; po.pbase = 0; po.x0 = po.y0 = po.x1 = po.y1 = 0; po.depth = 0.f; po.fits = false;
     const ViewRecord vrec = load_view_record(kp.views, v);
     const float *view = vrec.view, *proj = vrec.proj;
     const size_t vg = (size_t)v * kp.P + g;
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                 tiles = (uint32_t)((x1 - x0) * (y1 - y0));
                 if (tiles > 0) {
                     radius = (int)my_radius;
+                    po.depth = pvz;
                     kp.xy[vg] = make_float2(px, py);
                     kp.depth[vg] = pvz;
                     kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacity);
@@ -568,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
     // test); k_scan_tiles raises the overflow flag from the cursors
     const bool fits = pbase + tiles <= (seg + 1u) * kp.seg_cap;
     if (g < kp.P) kp.pair_off[vg] = fits ? pbase : kp.cap;
+    po.tiles = tiles; po.pbase = pbase; po.x0 = x0; po.y0 = y0; po.x1 = x1; po.y1 = y1; po.fits = fits;
 
     // ---- per-tile counts and the rank of every pair inside its tile ----
     // Gaussians of one workgroup are usually neighbours on the mesh, so they hit few distinct tiles: count them in an
@@ -608,6 +612,20 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
                 if (fits) prank[pr] = r;
             }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
+{
+    const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
+    uint32_t gb, vb;
+#if T4D_GB_ORDER & 1
+    if (!block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, gb, vb)) return;          // padding of the last group of eight
+#else
+    vb = blockIdx.x / nblocks; gb = blockIdx.x - vb * nblocks;
+    if (vb >= (uint32_t)kp.V) return;
+#endif
+    PreOut po;
+    preprocess_body(kp, gb, vb, po);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -881,6 +899,111 @@ __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
     const unsigned long long key = ((unsigned long long)__float_as_uint(dep) << 32) | (uint32_t)g;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++, pr++) {
+            if (pr >= kp.cap) return;
+            const uint32_t pos = s_off[y * kp.gx + x] + kp.pair_rank[pr];
+            if (pos < kp.cap) kp.keys[pos] = key;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The whole binning front end of ONE small view (Topo4D's own call shape) in one launch: preprocess, then - behind one grid-wide
+// barrier - what k_scan_scatter_small does, on the values the threads still hold (tile rectangle, depth, pair slots).  The
+// launch is at most 128 workgroups of 256 threads: all of them are resident at once, so a spin barrier is safe.  What crosses
+// the barrier between workgroups are the per-tile counts and the slot cursors, both products of RETURNING device-scope atomics
+// (performed at the memory side, complete before their result is used) and read back with agent-scope atomic loads: no fence,
+// no L2 write-back (a __threadfence() per workgroup cost the round-3 experiment 10x its gain).  One launch and one trip
+// through memory less per forward: 9.9 + 7.7 us -> see DESIGN.md section 5.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(kBlock) void k_front_small(const KP kp)
+{
+    __shared__ uint32_t s_off[kSmallTiles];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_bcnt[kBuckets], s_bpre[kBuckets];
+    __shared__ uint32_t s_longest[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t nb8 = gaussian_grid(kp.P, 1), nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
+    PreOut po;
+    po.tiles = 0; po.pbase = 0; po.x0 = po.y0 = po.x1 = po.y1 = 0; po.depth = 0.f; po.fits = false;
+    if (blockIdx.x < nblocks) preprocess_body(kp, blockIdx.x, 0u, po);
+    // ---- the grid-wide barrier: every count of this workgroup has been added (the atomics returned) when thread 0 arrives
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(&kp.status->grid_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (load_agent(&kp.status->grid_sync) < nb8 + 1u) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    // ---- exclusive scan of the tile counts: thread t owns tiles 4t .. 4t + 3 (as k_scan_scatter_small)
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c[j] = 4 * tid + j < kp.T ? load_agent(&kp.tile_count[4 * tid + j]) : 0u;
+    const uint32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+    const uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63) s_wtot[wave] = incl;
+    if (tid < kBuckets) s_bcnt[tid] = 0;
+    __syncthreads();
+    uint32_t base = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t x = s_wtot[w];
+        if (w < wave) base += x;
+        total += x;
+    }
+    uint32_t off[4];
+    off[0] = base; off[1] = off[0] + c[0]; off[2] = off[1] + c[1]; off[3] = off[2] + c[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_off[4 * tid + j] = off[j];
+    if (blockIdx.x == nb8) {
+        // ---- the scan kernel's other products, and the work items
+        uint32_t longest = max(max(c[0], c[1]), max(c[2], c[3]));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
+        if (lane == 0) s_longest[wave] = longest;
+        int bk[4];
+        uint32_t rank[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bk[j] = count_bucket(c[j]);
+            rank[j] = 4 * tid + j < kp.T ? atomicAdd(&s_bcnt[bk[j]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            for (int k = 0; k < kBuckets; k++) { s_bpre[k] = acc; acc += s_bcnt[k]; }
+        }
+        __syncthreads();
+        if (tid < kBuckets) kp.bucket_fill[tid] = s_bcnt[tid];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = 4 * tid + j;
+            if (t < kp.T) {
+                kp.tile_off[t] = off[j];
+                const uint32_t n = off[j] >= kp.cap ? 0u : min(c[j], kp.cap - off[j]);
+                kp.items[s_bpre[bk[j]] + rank[j]] = make_uint4((uint32_t)t, off[j], n, c[j]);       // view 0: id = tile
+                write_segment_slots(kp, (uint32_t)t, off[j], n);
+            }
+        }
+        if (tid == 0) {
+            kp.view_total[0] = total;
+            uint32_t fill = 0;                                  // fullest pair-slot segment (see k_scan_tiles)
+            for (uint32_t k = 0; k < kp.nseg; k++) fill = max(fill, load_agent(&kp.view_cursor[k]));
+            const unsigned long long need = max((unsigned long long)total, (unsigned long long)fill * kp.nseg);
+            kp.status->max_pairs = (uint32_t)min(need, 0xffffffffull);
+            kp.status->total_pairs = (unsigned long long)total;
+            kp.status->max_tile_pairs = max(max(s_longest[0], s_longest[1]), max(s_longest[2], s_longest[3]));
+            if (total > kp.cap || fill > kp.seg_cap) kp.status->overflow = 1u;
+        }
+        return;
+    }
+    __syncthreads();
+    // ---- scatter, from the registers of the preprocess pass (a Gaussian that lost its slots - arena overflow - scatters nothing)
+    if (po.tiles == 0u || !po.fits) return;
+    const int g = (int)blockIdx.x * kBlock + tid;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(po.depth) << 32) | (uint32_t)g;
+    uint32_t pr = po.pbase;
+    for (int y = po.y0; y < po.y1; y++)
+        for (int x = po.x0; x < po.x1; x++, pr++) {
             if (pr >= kp.cap) return;
             const uint32_t pos = s_off[y * kp.gx + x] + kp.pair_rank[pr];
             if (pos < kp.cap) kp.keys[pos] = key;
@@ -2790,13 +2913,17 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     kp.out_color = io->out_color; kp.out_depth = io->out_depth; kp.out_alpha = io->out_alpha; kp.radii = io->out_radii;
 
     T4D_HIP(hipMemsetAsync(st, 0, L.zero_end, stream));
+    // one view of at most 1,024 tiles (Topo4D's own call shape): scan and scatter are ONE launch (k_scan_scatter_small), and with
+    // at most 128 workgroups of Gaussians (all resident at once) preprocess joins them behind a grid-wide barrier (k_front_small)
+    const bool small_view = p.n_views == 1 && kp.T <= kSmallTiles && getenv("T4D_NO_SMALL_VIEW") == nullptr;
+    const bool front = small_view && gaussian_grid(p.P, 1) + 1u <= 128u && getenv("T4D_NO_FRONT_FUSION") == nullptr;
     { ProfScope ps_(stream, K_PREPROCESS);
-    hipLaunchKernelGGL(k_preprocess, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
+    if (front) hipLaunchKernelGGL(k_front_small, dim3(gaussian_grid(p.P, 1) + 1), dim3(kBlock), 0, stream, kp);
+    else hipLaunchKernelGGL(k_preprocess, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_preprocess");
-    // one view of at most 1,024 tiles (Topo4D's own call shape): scan and scatter are ONE launch (k_scan_scatter_small)
-    const bool small_view = p.n_views == 1 && kp.T <= kSmallTiles && getenv("T4D_NO_SMALL_VIEW") == nullptr;
-    if (small_view) {
+    if (front) {
+    } else if (small_view) {
         ProfScope ps_(stream, K_SCATTER);
         hipLaunchKernelGGL(k_scan_scatter_small, dim3(gaussian_grid(p.P, 1) + 1), dim3(kBlock), 0, stream, kp);
     } else {
