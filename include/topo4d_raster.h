@@ -158,6 +158,13 @@ size_t t4d_view_dot_scratch_bytes(int32_t n_views);
 int t4d_view_dot(int32_t n_views, int64_t n_per_view, const float *a, const float *b, float *out, void *scratch,
                  void *hip_stream);
 
+/* The gradient of a loss that ADDS per-view terms (rasterize_views: one launch set per frame, one optimiser step per frame):
+ * dst[k][i] = sum over v < n_views of src[k][v * n_per_view[k] + i], v ascending (deterministic), for up to T4D_SUM_MAX_TENSORS
+ * per-view gradient tensors of t4d_rasterize_backward in ONE launch (six torch reductions otherwise).  NULL entries are skipped. */
+#define T4D_SUM_MAX_TENSORS 8
+int t4d_sum_views(int32_t n_views, int32_t n_tensors, const float *const *src, float *const *dst, const int64_t *n_per_view,
+                  void *hip_stream);
+
 /* Fused photometric loss of Topo4D's render loop, forward AND gradient in one call (train.py:310,315;
  * helpers.py:115-116 l1_loss_v1; external.py:73-116 calc_ssim):
  *     im' = exp(cam_m[v,c]) * im + cam_c[v,c];   loss[v] = 0.8*mean|im'-gt| + 0.2*(1 - mean SSIM_11x11(im', gt))

@@ -304,3 +304,24 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
     finally:
         topo4d_amd.set_sync_mode("checked")
         rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
+
+
+def test_view_summed_gradients_in_one_launch():
+    """t4d_sum_views: the view-summed gradients rasterize_views returns (one launch instead of six torch reductions), v ascending."""
+    from topo4d_amd import rasterizer
+    g = torch.Generator().manual_seed(5)
+    V = 7
+    per_view = {"means3D": torch.randn(V, 1001, 3, generator=g).cuda(), "means2D": torch.randn(V, 1001, 3, generator=g).cuda(),
+                "opacities": torch.randn(V, 1001, 1, generator=g).cuda(), "colors_precomp": None, "shs": torch.randn(V, 1001, 16, 3, generator=g).cuda(),
+                "scales": torch.randn(V, 1001, 3, generator=g).cuda(), "rotations": torch.randn(V, 1001, 4, generator=g).cuda(), "cov3D_precomp": None}
+    out = rasterizer._sum_views(per_view, V, need_means2D=False)
+    assert out["colors_precomp"] is None and out["cov3D_precomp"] is None and out["means2D"] is None
+    for k, t in per_view.items():
+        if t is None or k == "means2D":
+            continue
+        ref = t[0].clone()
+        for v in range(1, V):                       # the kernel's order: v ascending, one rounding per addition
+            ref += t[v]
+        assert out[k].shape == t.shape[1:] and torch.equal(out[k], ref), k
+    out2 = rasterizer._sum_views(per_view, V, need_means2D=True)
+    assert torch.equal(out2["means2D"], sum(per_view["means2D"][v] for v in range(V)))

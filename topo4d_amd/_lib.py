@@ -31,6 +31,7 @@ EXPORTS = (
     "t4d_texture_bake", "t4d_texture_render_colors", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
     "t4d_masked_l1_loss", "t4d_masked_l1_scratch_bytes",
     "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
+    "t4d_sum_views",
 )
 
 
@@ -113,6 +114,8 @@ def load():
     lib.t4d_debug_state_layout.argtypes = [C.POINTER(T4DProblem), C.c_int, C.POINTER(C.c_uint64), C.c_int]
     lib.t4d_view_dot_scratch_bytes.restype = C.c_size_t
     lib.t4d_view_dot_scratch_bytes.argtypes = [C.c_int32]
+    lib.t4d_sum_views.restype = C.c_int
+    lib.t4d_sum_views.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
     lib.t4d_view_dot.restype = C.c_int
     lib.t4d_view_dot.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.t4d_texture_bake_scratch_bytes.restype = C.c_size_t

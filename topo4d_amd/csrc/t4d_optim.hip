@@ -261,3 +261,68 @@ T4D_EXPORT int t4d_activate_backward(int64_t P, const float *unnorm_rotations, c
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_activate_backward launch: %s", hipGetErrorString(e));
     return T4D_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// view-summed gradients (include/topo4d_raster.h: t4d_sum_views)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct SumArgs {
+    const float *src[T4D_SUM_MAX_TENSORS];
+    float *dst[T4D_SUM_MAX_TENSORS];
+    long long n[T4D_SUM_MAX_TENSORS];
+    long long first_block[T4D_SUM_MAX_TENSORS + 1];
+    int V, count;
+};
+
+__global__ __launch_bounds__(kBlock) void k_sum_views(const SumArgs a)
+{
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < T4D_SUM_MAX_TENSORS; i++)
+        if (i < a.count && (long long)blockIdx.x >= a.first_block[i]) k = i;
+    const long long n = a.n[k];
+    const long long i4 = (((long long)blockIdx.x - a.first_block[k]) * kBlock + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const float *s = a.src[k];
+    if (i4 + 4 <= n && (n & 3) == 0 && (((uintptr_t)s | (uintptr_t)a.dst[k]) & 15) == 0) {
+        float4 acc = *reinterpret_cast<const float4 *>(s + i4);
+        for (int v = 1; v < a.V; v++) {
+            const float4 x = *reinterpret_cast<const float4 *>(s + (long long)v * n + i4);
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        *reinterpret_cast<float4 *>(a.dst[k] + i4) = acc;
+    } else {
+        for (long long i = i4; i < min(i4 + 4, n); i++) {
+            float acc = s[i];
+            for (int v = 1; v < a.V; v++) acc += s[(long long)v * n + i];
+            a.dst[k][i] = acc;
+        }
+    }
+}
+}  // namespace
+
+T4D_EXPORT int t4d_sum_views(int32_t n_views, int32_t n_tensors, const float *const *src, float *const *dst, const int64_t *n_per_view,
+                             void *hip_stream)
+{
+    if (n_views < 1 || n_tensors < 1 || n_tensors > T4D_SUM_MAX_TENSORS || !src || !dst || !n_per_view)
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_sum_views: bad arguments%s", "");
+    SumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.V = n_views;
+    long long blocks = 0;
+    for (int k = 0; k < n_tensors; k++) {
+        if (!src[k] || !dst[k] || n_per_view[k] <= 0) continue;
+        a.src[a.count] = src[k]; a.dst[a.count] = dst[k]; a.n[a.count] = n_per_view[k];
+        a.first_block[a.count] = blocks;
+        blocks += (n_per_view[k] + 4 * kBlock - 1) / (4 * kBlock);
+        a.count++;
+    }
+    a.first_block[a.count] = blocks;
+    if (a.count == 0) return T4D_OK;
+    if (blocks > 0x7fffffffLL) return t4d_internal_fail(T4D_ERR_ARG, "t4d_sum_views: too many elements%s", "");
+    hipLaunchKernelGGL(k_sum_views, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_sum_views launch: %s", hipGetErrorString(e));
+    return T4D_OK;
+}

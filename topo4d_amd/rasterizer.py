@@ -658,13 +658,35 @@ class _RasterizeViews(torch.autograd.Function):
             go = g["opacities"]
             return (g["means3D"], d2, g["shs"], g["colors_precomp"], go if go.shape == shpo else go.reshape(shpo),
                     g["scales"], g["rotations"], g["cov3D_precomp"], None)
-        red = (lambda t: None if t is None else t.sum(0)) if batch.V > 1 else \
-              (lambda t: None if t is None else t[0])
+        if batch.V > 1:
+            g = _sum_views(g, batch.V, need_means2D=shp2 is not None and ctx.needs_input_grad[1])
+            red = lambda t: t                # already summed over the views, in ONE launch (t4d_sum_views)
+        else:
+            red = lambda t: None if t is None else t[0]
         d_means2D = None
         if shp2 is not None and ctx.needs_input_grad[1]:
             d_means2D = red(g["means2D"]).reshape(shp2)
         return (red(g["means3D"]).reshape(shp3), d_means2D, red(g["shs"]), red(g["colors_precomp"]),
                 red(g["opacities"]).reshape(shpo), red(g["scales"]), red(g["rotations"]), red(g["cov3D_precomp"]), None)
+
+
+def _sum_views(g, V: int, need_means2D: bool):
+    """dict of per-view gradients [V,P,...] -> dict of view-summed gradients [P,...] (None stays None), one launch."""
+    lib = _lib.load()
+    names = [k for k, t in g.items() if t is not None and (k != "means2D" or need_means2D)]
+    out = {k: None for k in g}
+    if not names:
+        return out
+    for k in names:
+        out[k] = torch.empty(g[k].shape[1:], dtype=_F32, device=g[k].device)
+    n = len(names)
+    src = (C.c_void_p * n)(*[g[k].data_ptr() for k in names])
+    dst = (C.c_void_p * n)(*[out[k].data_ptr() for k in names])
+    cnt = (C.c_int64 * n)(*[out[k].numel() for k in names])
+    rc = lib.t4d_sum_views(V, n, src, dst, cnt, _raw_stream(g[names[0]].device))
+    if rc != T4D_OK:
+        raise RuntimeError(f"t4d_sum_views failed (code {rc}): {_lib.last_error()}")
+    return out
 
 
 def _none_if_empty(t):
