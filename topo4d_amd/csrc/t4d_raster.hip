@@ -1623,8 +1623,11 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 const float4 head = *reinterpret_cast<const float4 *>(s_rec + (((sub * kSubChunks + c4) << 6) + lane) * kRec);
                 wave_touch_masks(make_float2(head.x, head.y), head.z, tx, ty, wave, mc);
             }
+            // a sub-block whose sixteen pixels have all finished takes no more splats: its row walks an empty list, and the wave
+            // steps as often as the longest list of the rows that still blend (silhouette tiles of a dense pass: thousands of
+            // pairs, a handful of unsaturated pixels)
 #pragma unroll
-            for (int r = 0; r < 4; r++) m[r][c4] = mc[r];
+            for (int r = 0; r < 4; r++) m[r][c4] = ((done_m >> (16 * r)) & 0xffffull) == 0xffffull ? 0ull : mc[r];
         }
         int nsteps = 0, cnts[4];
 #pragma unroll
