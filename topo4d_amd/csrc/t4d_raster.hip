@@ -1466,7 +1466,10 @@ __device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t
 #define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_FWD_WAVES, LAT ? 2 : T4D_FWD_WAVES)))
 // FB: splats staged per batch.  SEG: the launch is small enough for the segmented backward (kSeg): visit lists are built and
 // walked per kSeg list positions, and the blend state at every such boundary is kept for the backward (write_snapshot).
-template <bool LAT, int FB, bool SEG>
+// PRUNE: finished sub-blocks walk empty lists (below).  A template parameter because its mere presence costs the 72-register
+// build 2.5 % at config 2 (register allocation, not executed instructions: a run-time gate that is never true costs the same),
+// where no list is long enough for it to matter: the host instantiates it for launches that may hold long lists.
+template <bool LAT, int FB, bool SEG, bool PRUNE>
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
     constexpr int kU = LAT ? 8 : 4;                  // steps per group
@@ -1614,6 +1617,15 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         for (int sub = 0; sub < kNSub; sub++) {      // (one round per batch unless SEG)
         const uint32_t sub_lo = b + (uint32_t)(sub * kSub);
         if (sub != 0 && !(sub_lo < n)) break;
+        // A sub-block whose sixteen pixels have all finished takes no more splats: its row walks an empty list, and the wave steps
+        // as often as the longest list of the rows that still blend (silhouette tiles of a dense pass hold thousands of pairs
+        // and a handful of unsaturated pixels: one view of 10^6 Gaussians 642 -> 298 us).  Scalar work is scarce (one scalar
+        // unit per CU): the question is asked once per round, and only where a pixel of the wave has finished at all.
+        uint32_t rows_done = 0u;
+        if (PRUNE && done_m != 0ull) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) rows_done |= (((done_m >> (16 * r)) & 0xffffull) == 0xffffull ? 1u : 0u) << r;
+        }
         // which of the staged splats can touch which of this wave's four sub-blocks (= DPP rows)
         unsigned long long m[4][kSubChunks];
 #pragma unroll
@@ -1622,12 +1634,13 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             if (sub_lo + ((uint32_t)c4 << 6) < n) {      // wave-uniform: short lists leave most chunks of a batch empty
                 const float4 head = *reinterpret_cast<const float4 *>(s_rec + (((sub * kSubChunks + c4) << 6) + lane) * kRec);
                 wave_touch_masks(make_float2(head.x, head.y), head.z, tx, ty, wave, mc);
-            }
-            // a sub-block whose sixteen pixels have all finished takes no more splats: its row walks an empty list, and the wave
-            // steps as often as the longest list of the rows that still blend (silhouette tiles of a dense pass: thousands of
-            // pairs, a handful of unsaturated pixels)
+                if (PRUNE && rows_done != 0u) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) m[r][c4] = ((done_m >> (16 * r)) & 0xffffull) == 0xffffull ? 0ull : mc[r];
+                    for (int r = 0; r < 4; r++) mc[r] = ((rows_done >> r) & 1u) ? 0ull : mc[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) m[r][c4] = mc[r];
         }
         int nsteps = 0, cnts[4];
 #pragma unroll
@@ -2981,11 +2994,15 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     const dim3 fgrid(kp.tile_blocks + kp.fill_blocks);
     const bool seg = kp.slots_per_view != 0u;        // small launch: snapshots for the segmented backward (kSeg)
     if (lat) {
-        if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, true>), fgrid, dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_fwd<true, kBlock, false>), fgrid, dim3(kBlock), 0, stream, kp);
+        if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, true, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_fwd<true, kBlock, false, true>), fgrid, dim3(kBlock), 0, stream, kp);
+    } else if (seg) {
+        hipLaunchKernelGGL((k_render_fwd<false, kBlock, true, true>), fgrid, dim3(kBlock), 0, stream, kp);
+    } else if (kp.long_bins_elsewhere && getenv("T4D_NO_PRUNE") == nullptr) {
+        // a big launch that may hold long lists (the caller has not passed T4D_FLAG_NO_LONG_BINS): a dense pass
+        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, false, true>), fgrid, dim3(kBlock), 0, stream, kp);
     } else {
-        if (seg) hipLaunchKernelGGL((k_render_fwd<false, kBlock, true>), fgrid, dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, false>), fgrid, dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, false, false>), fgrid, dim3(kBlock), 0, stream, kp);
     }
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
