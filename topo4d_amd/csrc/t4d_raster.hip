@@ -1463,7 +1463,10 @@ __device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t
 // group with all their LDS reads issued up front, no exec-mask branches between the steps, one backward slab per DPP row
 // (no same-splat conflicts to serialise).  Per-pixel arithmetic and its order are IDENTICAL in both builds: forward
 // outputs are bit-equal; the backward's partial sums are added up in a different (still fixed) order.
-#define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_FWD_WAVES, LAT ? 2 : T4D_FWD_WAVES)))
+#ifndef T4D_LAT_WAVES
+#define T4D_LAT_WAVES 2          // most waves per SIMD the latency build is compiled for (register budget 512 / this)
+#endif
+#define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_FWD_WAVES, LAT ? T4D_LAT_WAVES : T4D_FWD_WAVES)))
 // FB: splats staged per batch.  SEG: the launch is small enough for the segmented backward (kSeg): visit lists are built and
 // walked per kSeg list positions, and the blend state at every such boundary is kept for the backward (write_snapshot).
 // PRUNE: finished sub-blocks walk empty lists (below).  A template parameter because its mere presence costs the 72-register
@@ -1866,8 +1869,10 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #ifndef T4D_BWD_WAVES
 #define T4D_BWD_WAVES 5                  // = workgroups per CU (30.8 KB of LDS each); 4 is 14 % slower, 6 spills (round-3 sweep)
 #endif
-// (the segmented build of small launches never has five workgroups per CU to place: four waves per SIMD, 128 registers, no spills)
-#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (SEG ? 4 : T4D_BWD_WAVES), LAT ? 2 : (SEG ? 4 : T4D_BWD_WAVES))))
+#ifndef T4D_SEG_WAVES
+#define T4D_SEG_WAVES 5          // (4 = 128 registers, no spills: config-2 scene 1 view 36.3 us, 3 views 64.4; 5: 37.4 / 59.3, 6 views 104.7 -> 95.6)
+#endif
+#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (SEG ? T4D_SEG_WAVES : T4D_BWD_WAVES), LAT ? 2 : (SEG ? T4D_SEG_WAVES : T4D_BWD_WAVES))))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
 constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the empty-tile share of cotangent_dot
 // LAT: the latency build (see k_render_fwd): one slab per DPP ROW instead of one per wave (82 KB of LDS: one workgroup per CU
