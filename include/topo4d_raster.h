@@ -59,9 +59,11 @@ enum {
                                   instead of rendering truncated tile lists (what upstream's num_rendered D2H does) */
     T4D_FLAG_DEBUG_SYNC = 2u,  /* `debug=True` of the settings tuple: synchronise + check after every kernel */
     T4D_FLAG_PREFILTERED = 4u, /* accepted for API parity (helpers.py:84 passes False); no effect */
-    T4D_FLAG_ASYNC_STATUS = 8u,/* forward, without CHECKED: `status` must point at PINNED host memory; the first 16 bytes
-                                  receive { uint32 overflow; uint32 max_pairs_per_view; uint64 total_pairs } by an
-                                  asynchronous copy enqueued behind the binning kernels — no host synchronisation */
+    T4D_FLAG_ASYNC_STATUS = 8u,/* forward, without CHECKED: `status` must point at PINNED (device-mapped) host memory; the first
+                                  16 bytes receive { uint32 overflow; uint32 max_pairs_per_view; uint64 total_pairs } without
+                                  any host synchronisation: written by the binning kernel itself (one view of at most 1,024
+                                  tiles; the two 8-byte words may land one after the other) or by an asynchronous copy
+                                  enqueued behind the binning kernels */
     T4D_FLAG_NO_LONG_BINS = 16u,/* forward: the caller knows (T4DStatus.max_tile_pairs of an earlier call on this scene) that no
                                   tile list exceeds 2048 pairs: the launch of the long-bin sort kernel is skipped.  Only a
                                   speed hint — longer bins that show up anyway are still sorted correctly, just slowly */

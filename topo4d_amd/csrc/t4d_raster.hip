@@ -203,6 +203,7 @@ struct KP {
     float *snap;             // [V * slots_per_view][kSnapFloats][256]
     uint32_t slots_per_view; // 0: this launch is not segmented
     uint32_t fused_sort;     // k_render_fwd<LAT = true> sorts its tile's bin itself (no k_sort_tiles launch)
+    unsigned long long *host_status;  // T4D_FLAG_ASYNC_STATUS on a one-view launch: the caller's pinned 16 bytes, written by the kernel itself
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -815,6 +816,17 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSmallTiles = 4 * kBlock;
 
+// T4D_FLAG_ASYNC_STATUS on a one-view launch: the 16-byte status { overflow, max pairs per view, total pairs } goes to the caller's
+// PINNED host memory straight from the thread that knows it - two system-scope stores instead of a copy kernel on the stream
+// (3-5 us of GPU time and a launch per forward of Topo4D's loop).  The host treats a block as landed when neither word holds its
+// sentinel, so the order of the two stores does not matter.
+__device__ __forceinline__ void publish_status(const KP &kp, const uint32_t overflow, const uint32_t max_pairs, const unsigned long long total)
+{
+    if (kp.host_status == nullptr) return;
+    __hip_atomic_store(&kp.host_status[1], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&kp.host_status[0], (unsigned long long)overflow | ((unsigned long long)max_pairs << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
 {
     __shared__ uint32_t s_off[kSmallTiles];
@@ -881,7 +893,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
             kp.status->max_pairs = (uint32_t)min(need, 0xffffffffull);
             kp.status->total_pairs = (unsigned long long)total;
             kp.status->max_tile_pairs = max(max(s_longest[0], s_longest[1]), max(s_longest[2], s_longest[3]));
-            if (total > kp.cap || fill > kp.seg_cap) kp.status->overflow = 1u;
+            const uint32_t ovf = (total > kp.cap || fill > kp.seg_cap) ? 1u : 0u;
+            if (ovf) kp.status->overflow = 1u;
+            publish_status(kp, ovf, (uint32_t)min(need, 0xffffffffull), (unsigned long long)total);
         }
         return;
     }
@@ -992,7 +1006,9 @@ __global__ __launch_bounds__(kBlock) void k_front_small(const KP kp)
             kp.status->max_pairs = (uint32_t)min(need, 0xffffffffull);
             kp.status->total_pairs = (unsigned long long)total;
             kp.status->max_tile_pairs = max(max(s_longest[0], s_longest[1]), max(s_longest[2], s_longest[3]));
-            if (total > kp.cap || fill > kp.seg_cap) kp.status->overflow = 1u;
+            const uint32_t ovf = (total > kp.cap || fill > kp.seg_cap) ? 1u : 0u;
+            if (ovf) kp.status->overflow = 1u;
+            publish_status(kp, ovf, (uint32_t)min(need, 0xffffffffull), (unsigned long long)total);
         }
         return;
     }
@@ -2933,6 +2949,18 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     kp.shs = io->shs;
     kp.out_color = io->out_color; kp.out_depth = io->out_depth; kp.out_alpha = io->out_alpha; kp.radii = io->out_radii;
 
+    // un-synchronised one-view call with a pinned status block: the binning kernel writes it itself (publish_status)
+    bool status_published = false;
+    if (!checked && (p.flags & T4D_FLAG_ASYNC_STATUS) && status && p.n_views == 1 && kp.T <= kSmallTiles &&
+        getenv("T4D_NO_SMALL_VIEW") == nullptr && getenv("T4D_STATUS_BY_COPY") == nullptr) {
+        void *dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, (void *)status, 0) == hipSuccess && dptr != nullptr) {
+            kp.host_status = (unsigned long long *)dptr;
+            status_published = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     T4D_HIP(hipMemsetAsync(st, 0, L.zero_end, stream));
     // one view of at most 1,024 tiles (Topo4D's own call shape): scan and scatter are ONE launch (k_scan_scatter_small), and with
     // at most 128 workgroups of Gaussians (all resident at once) preprocess joins them behind a grid-wide barrier (k_front_small)
@@ -2964,7 +2992,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
             status->max_tile_pairs = (int32_t)min(hs.max_tile_pairs, 0x7fffffffu);
         }
         if (hs.overflow) return fail(T4D_ERR_PAIR_OVERFLOW, "pair_capacity too small for this scene");
-    } else if ((p.flags & T4D_FLAG_ASYNC_STATUS) && status) {
+    } else if ((p.flags & T4D_FLAG_ASYNC_STATUS) && status && !status_published) {
         // no synchronisation: the 16-byte raw status block lands in the caller's PINNED host memory once the scan kernel
         // has run; the caller looks at it after an event of its own (topo4d_amd's "auto" sync mode does, one call later)
         T4D_HIP(hipMemcpyAsync((void *)status, st + L.status, 16, hipMemcpyDeviceToHost, stream));     // the documented 16 bytes
