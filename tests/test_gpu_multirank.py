@@ -87,6 +87,20 @@ def test_rccl_branch_with_a_process_group_of_one_rank():
                                   np.asarray(plain["gathered_losses_first_steps"], np.float32))
 
 
+def test_the_drivers_two_gpu_command_carries_every_multi_rank_object():
+    """The command the driver launches for N = 2 (no --no-extras): `value` (weak, frame-sharded), `strong` (the 64-frame job) AND
+    `view_sharded` (12 views per rank and frame) all come out of one line; the one-GPU-only probes stay out of it."""
+    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm-s", "0"], env)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["value"] > 0 and two["repeats"]["regions"] == 5
+    assert two["strong"]["job_frame_steps"] == 64 and two["strong"]["value"] > 0
+    vs = two["view_sharded"]
+    assert vs["views_per_rank"] == 12 and vs["value"] > 0 and "view-sharded x2" in vs["parallelism"]
+    for k in ("single_view", "small_v", "forecast", "drop_in", "full_iteration", "c4", "dense_1m", "cpu_baseline"):
+        assert two[k] is None, k
+
+
 def test_view_sharded_two_rank_dry_run_equals_the_24_view_launch():
     """`bench.py --shard views` (the split of SURVEY 8e / BASELINE config 3: rank r renders views r::N of every frame): two ranks
     share the test GPU, gloo stands in for RCCL.  A view's loss scalar and its gradients do not depend on which other views
