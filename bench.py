@@ -182,6 +182,12 @@ class Workload:
         self.V = V = len(mine)
         views = pack_views(cams, dev)
         self.dc = dc.to(dev).contiguous()
+        # T4D_BENCH_DA=1 (experiments; never the default): depth and alpha cotangents too - the backward's DA = true instantiation
+        # (Topo4D discards depth and alpha, train.py:307: its backward never runs it)
+        self.dd = self.da = None
+        if os.environ.get("T4D_BENCH_DA") == "1":
+            _, dd, da = scene.output_cotangents(self.full_views, H, W, seed=0, depth_alpha=True)
+            self.dd, self.da = dd[mine].to(dev).contiguous(), da[mine].to(dev).contiguous()
         # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
         self.n_frames = n_frames
         my_frames = t4d_dist.shard_units(n_frames, rank, world) if view_shard is None else list(range(n_frames))
@@ -222,7 +228,7 @@ class Workload:
             b.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv.get("colors_precomp"), rv.get("shs"))
             # per-view scalar loss term <colour, dL/dcolour>: the backward's replay ends holding exactly this inner product per
             # pixel, so it comes out of t4d_rasterize_backward (cotangent_dot), not out of a second pass over both images
-            g = b.backward(self.dc, cotangent_dot=losses)
+            g = b.backward(self.dc, self.dd, self.da, cotangent_dot=losses)
             if self.allreduce_grads:
                 # data-parallel training step over a view shard: the view-summed parameter gradients are summed over the ranks
                 # (~14 floats x P; changes train.py:661-673's one-Adam-step-per-view schedule, so it is optional)

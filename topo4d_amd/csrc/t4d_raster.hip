@@ -1888,7 +1888,11 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #ifndef T4D_SEG_WAVES
 #define T4D_SEG_WAVES 5          // (4 = 128 registers, no spills: config-2 scene 1 view 36.3 us, 3 views 64.4; 5: 37.4 / 59.3, 6 views 104.7 -> 95.6)
 #endif
-#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (SEG ? T4D_SEG_WAVES : T4D_BWD_WAVES), LAT ? 2 : (SEG ? T4D_SEG_WAVES : T4D_BWD_WAVES))))
+#ifndef T4D_BWD_DA_WAVES
+#define T4D_BWD_DA_WAVES T4D_BWD_WAVES
+#endif
+#define T4D_BWD_NW (LAT ? 2 : (SEG ? T4D_SEG_WAVES : (DA ? T4D_BWD_DA_WAVES : T4D_BWD_WAVES)))
+#define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_BWD_NW, T4D_BWD_NW)))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
 constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the empty-tile share of cotangent_dot
 // LAT: the latency build (see k_render_fwd): one slab per DPP ROW instead of one per wave (82 KB of LDS: one workgroup per CU
