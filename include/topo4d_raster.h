@@ -67,9 +67,12 @@ enum {
     T4D_FLAG_NO_LONG_BINS = 16u,/* forward: the caller knows (T4DStatus.max_tile_pairs of an earlier call on this scene) that no
                                   tile list exceeds 2048 pairs: the launch of the long-bin sort kernel is skipped.  Only a
                                   speed hint — longer bins that show up anyway are still sorted correctly, just slowly */
-    T4D_FLAG_SHORT_BINS = 32u  /* forward: ... and that none exceeds 512 pairs (the one-pass ranking sort): a small launch then
+    T4D_FLAG_SHORT_BINS = 32u, /* forward: ... and that none exceeds 512 pairs (the one-pass ranking sort): a small launch then
                                   sorts every bin inside the render workgroup of its tile instead of launching a sort kernel.
                                   A speed hint like the one above */
+    T4D_FLAG_LONG_LISTS = 64u  /* forward: the caller knows that some tile list exceeds 1,024 pairs: launches of up to 24 x CUs
+                                  tiles (instead of 12 x) run the latency build of the forward, which such a list bounds.
+                                  A speed hint */
 };
 
 typedef struct T4DProblem {

@@ -2816,11 +2816,14 @@ bool latency_launch(int n_tiles)
 // The FORWARD's latency build (registers for instruction-level parallelism, its own tile's bin sorted in the workgroup, records
 // of the next batch in flight during the walk) stays ahead of the throughput build for much larger launches than the
 // backward's did (which needs 82 KiB of LDS per workgroup): T4D_FWD_LATENCY_TILES overrides, T4D_LATENCY_TILES too (tests).
-bool latency_launch_fwd(int n_tiles)
+bool latency_launch_fwd(int n_tiles, uint32_t flags)
 {
     const char *e = getenv("T4D_FWD_LATENCY_TILES");
     if (!e) e = getenv("T4D_LATENCY_TILES");
-    return n_tiles <= (e ? atoi(e) : 12 * device_cus());
+    // Where the two builds cross depends on the scene: a launch that waits for one long list (the config-2 scene: 1,400 pairs in a
+    // tile) is better off in the latency build up to ~6 views (4 views: 67 against 82 us), a launch of many short lists (Topo4D's
+    // scene, longest 470) only up to 4 (5 views: 48 against 35 us).  The caller's T4D_FLAG_LONG_LISTS says which it is.
+    return n_tiles <= (e ? atoi(e) : ((flags & T4D_FLAG_LONG_LISTS) ? 24 : 12) * device_cus());
 }
 
 int check_problem(const T4DProblem *p)
@@ -3009,7 +3012,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // Who sorts the bins.  A big launch: k_sort_tiles on 256 threads.  A small launch (at most kSegMaxTiles tiles) waits for its
     // longest bin: 1024 threads per bin - unless the forward runs its latency build AND the caller knows that every bin fits the
     // one-pass ranking sort (T4D_FLAG_SHORT_BINS): then the render workgroup of a tile sorts its own bin (no launch at all).
-    const bool lat = latency_launch_fwd(kp.T * p.n_views);
+    const bool lat = latency_launch_fwd(kp.T * p.n_views, p.flags);
     kp.fused_sort = (lat && (p.flags & T4D_FLAG_SHORT_BINS) != 0 && getenv("T4D_NO_FUSED_SORT") == nullptr) ? 1u : 0u;
     if (!kp.fused_sort) {
         ProfScope ps_(stream, K_SORT_TILES);

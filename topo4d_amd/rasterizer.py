@@ -385,6 +385,8 @@ class ViewBatch:
         # tile lists of this scene size stayed well below the LDS sort buffer (2048) so far: skip the long-bin sort launch
         # (a speed hint only - see include/topo4d_raster.h)
         longest = _LONGEST_BIN.get((self.device.index, P, self.H, self.W))
+        if longest is not None and longest > 1024:
+            flags |= _lib.T4D_FLAG_LONG_LISTS     # some tile list bounds a small launch: the latency forward for up to 24 x CUs tiles
         if longest is not None and longest <= 1536:
             flags |= T4D_FLAG_NO_LONG_BINS
             if longest <= 448:            # ... and below the one-pass ranking sort (512): small launches sort inside the render kernel
