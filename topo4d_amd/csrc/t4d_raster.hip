@@ -82,7 +82,10 @@ constexpr int kCursorSegs = 8;       // pair-slot cursors per view (same-address
 // starts from the transmittance in front of position (j+1) kSeg and from the suffix colour (C_final - C_prefix) / T, both taken
 // from the snapshots instead of from the replay of everything behind.  No running value of the replay feeds a discrete
 // decision, so the segments take the decisions of the whole-list replay; sums differ by rounding only.
-constexpr int kSeg = 128;            // list positions per backward segment (= kBwdBatch: one staged batch per segment)
+#ifndef T4D_SEG
+#define T4D_SEG 128
+#endif
+constexpr int kSeg = T4D_SEG;        // list positions per backward segment (= kBwdBatch: one staged batch per segment)
 constexpr int kSegMaxTiles = 8192;   // launches of at most this many tiles (V * T) run the segmented backward
 constexpr int kSnapFloats = 5;       // T, C0, C1, C2, D per pixel and boundary
 
