@@ -338,10 +338,11 @@ def load_profile_json(name, config, kernel):
 
 def counters_provenance(config, lanes_key=None):
     """The rocprofv3 counters in profiles/*.json were taken by separate runs (tools/prof.sh, tools/count_lanes.py): "current" when
-    they were taken on the kernel source this run executes (sha256 of csrc/t4d_raster.hip), otherwise "stale"."""
-    import hashlib
+    they were taken on the kernel source this run executes (sha256 over csrc/t4d_raster.hip and its t4d_raster_*.h parts:
+    topo4d_amd.build.raster_source_sha256), otherwise "stale"."""
     try:
-        now = hashlib.sha256(open(os.path.join(ROOT, "topo4d_amd", "csrc", "t4d_raster.hip"), "rb").read()).hexdigest()
+        from topo4d_amd.build import raster_source_sha256
+        now = raster_source_sha256()
     except OSError:
         return {"kernel_source_sha256": None}
     out = {"kernel_source_sha256": now[:16]}

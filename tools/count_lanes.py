@@ -33,9 +33,8 @@ for name, o in (("bwd", 0), ("fwd", 8)):
                  "lanes_per_row_visit": round(lanes / max(1, visits), 2),
                  "steps_per_wave_batch": round(steps / max(1, batches), 1),
                  "row_visits_per_pair": round(visits / max(1, int(st.total_pairs)), 2)}
-import hashlib
-out["_kernel_source_sha256"] = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "topo4d_amd", "csrc",
-                                                              "t4d_raster.hip"), "rb").read()).hexdigest()
+from topo4d_amd.build import raster_source_sha256
+out["_kernel_source_sha256"] = raster_source_sha256()
 print(json.dumps(out))
 if "--merge" in sys.argv:                      # profiles/lanes.json: what bench.py reads for roofline.useful_lane_fraction
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "lanes.json")

@@ -12,7 +12,7 @@ for name, key in (("traffic.json", "traffic"), ("valu.json", "valu")):
                                 "(quad-cycles) * 4 / (1024 SIMDs * kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs")
     cur[cfg] = c[key]
     cur.setdefault("_source", {})[cfg] = os.path.basename(os.path.normpath(src))
-    # sha256 of csrc/t4d_raster.hip when the counters were taken: bench.py compares it with the source it runs
+    # sha256 of the rasterizer sources (topo4d_amd.build.raster_source_sha256) when the counters were taken: bench.py compares it with the source it runs
     cur.setdefault("_kernel_source_sha256", {})[cfg] = c.get("_kernel_source_sha256")
     json.dump(cur, open(path, "w"), indent=1)
     print("updated", path)

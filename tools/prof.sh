@@ -23,10 +23,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/pmc3 -o p 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/pmc4 -o p -- $B $SHORT "$@" > $OUT/bench_pmc4.log 2>&1
 python $ROOT/tools/summarize_prof.py $RAW $OUT > /dev/null
 python - <<PY
-import hashlib, json
+import json, sys
+sys.path.insert(0, "$ROOT")
+from topo4d_amd.build import raster_source_sha256
 p = "$OUT/counters.json"
 c = json.load(open(p))
-c["_kernel_source_sha256"] = hashlib.sha256(open("$ROOT/topo4d_amd/csrc/t4d_raster.hip", "rb").read()).hexdigest()
+c["_kernel_source_sha256"] = raster_source_sha256()
 json.dump(c, open(p, "w"), indent=1)
 PY
 ls $OUT

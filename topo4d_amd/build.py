@@ -26,6 +26,16 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def raster_source_sha256() -> str:
+    """sha256 over the rasterizer's translation unit - csrc/t4d_raster.hip and the t4d_raster_*.h parts it includes, in name
+    order: the stamp the committed rocprofv3 counters carry (tools/prof.sh, tools/count_lanes.py) and bench.py compares."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "t4d_raster*.hip")) + glob.glob(os.path.join(CSRC, "t4d_raster*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
