@@ -212,6 +212,40 @@ def test_c2_full_size_sampled_views_against_c_oracle(c2):
         check_grads(c2["g"], gref, v)
 
 
+@pytest.mark.parametrize("views", [(0, 8, 16), (13,)])
+def test_c2_scene_in_the_view_sharded_rank_shape(c2, views):
+    """What one rank of BASELINE config 3 launches: three views (or one) of the full C2 scene.  That launch takes
+    the other build of every stage - one-launch front end (1 view) or the small scan, the 1024-thread sort, the latency forward
+    with snapshots, the depth-segmented backward - than the 24-view launch of the fixture does.  A view does not know which other
+    views share its launch: binning state and images are bit-equal to the 24-view launch's, the gradients agree with it to
+    summation-order rounding and with the C oracle to the parity tolerance."""
+    idx = list(views)
+    cams = [c2["cams"][v] for v in idx]
+    dc, dd, da = c2["dc"][idx], c2["dd"][idx], c2["da"][idx]
+    out, g, batch = util.hip_render(cams, c2["rv"], dc, dd, da)
+    st = util.decode_state(batch)
+    assert st["status"][0] == 0
+    assert batch.prob.n_views == len(idx)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(out[k], c2["out"][k][idx])
+    for k in ("tile_count", "view_total", "n_contrib", "final_T"):
+        np.testing.assert_array_equal(st[k], c2["st"][k][idx])
+    for i, v in enumerate(idx):                                      # sorted lists: same keys in the same order
+        for t in np.nonzero(st["tile_count"][i])[0][::37]:
+            n = st["tile_count"][i][t]
+            np.testing.assert_array_equal(st["keys"][i][st["tile_off"][i][t]:][:n],
+                                          c2["st"]["keys"][v][c2["st"]["tile_off"][v][t]:][:n])
+    assert st["tile_count"].max() > 128                              # lists long enough to be cut into several segments
+    for k in g:
+        if g[k] is None:
+            continue
+        a, b = c2["g"][k][idx].astype(np.float64), g[k].astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max() + 1e-12, k
+    r, gref = util.c_oracle_render(cams[0], c2["rv"], dc[0], dd[0], da[0])
+    check_outputs(out, r.color, r.depth, r.alpha, 0)
+    check_grads(g, gref, 0)
+
+
 def test_module_accepts_what_upstream_accepts():
     """Non-contiguous / float64 inputs, [P] vs [P,1] opacities, SH and precomputed-covariance paths, no_grad renders
     (train.py:463,484), all through the drop-in module."""
