@@ -113,10 +113,11 @@ def test_masked_l1_matches_reference_golden_g8_and_torch():
 
 
 @pytest.mark.parametrize("shape", [(1, 512, 375), (2, 97, 210), (24, 128, 128)])
-def test_two_wave_roles_equal_one_thread_per_column(shape, monkeypatch):
-    """k_photo_split (single views: first-stage waves and second-stage waves per strip) and k_photo_fused (batches: one thread
-    per column for both stages) do the same arithmetic in the same order: loss, dL/dim and the camera gradients must be
-    bit-identical whichever of them the launch picks (T4D_PH_SPLIT forces one)."""
+def test_gradient_does_not_depend_on_the_strip_partition(shape, monkeypatch):
+    """k_photo_stream cuts a plane into strips of kFT - 20 columns and segments of rows (T4D_PH_THREADS / T4D_PH_ROWS force
+    them).  A pixel's arithmetic and its order do not depend on which strip or segment it falls in: dL/dim must be
+    bit-identical under every partition; the loss and the camera gradients are sums over another fixed partition and agree to
+    rounding."""
     V, H, W = shape
     g = torch.Generator().manual_seed(5)
     im = torch.rand(V, 3, H, W, generator=g).cuda()
@@ -124,13 +125,19 @@ def test_two_wave_roles_equal_one_thread_per_column(shape, monkeypatch):
     cm = (torch.randn(V, 3, generator=g) * 0.1).cuda()
     cc = (torch.randn(V, 3, generator=g) * 0.05).cuda()
     out = []
-    for split in ("1", "0"):
-        monkeypatch.setenv("T4D_PH_SPLIT", split)
+    for threads, rows in (("", ""), ("64", "16"), ("128", "37"), ("192", "64"), ("256", "512")):
+        if threads:
+            monkeypatch.setenv("T4D_PH_THREADS", threads)
+            monkeypatch.setenv("T4D_PH_ROWS", rows)
         a = [t.clone().requires_grad_(True) for t in (im, cm, cc)]
         l = loss.photometric_loss(a[0], gt, a[1], a[2])
         l.sum().backward()
         out.append([l.detach().cpu().numpy()] + [t.grad.cpu().numpy() for t in a])
-    monkeypatch.delenv("T4D_PH_SPLIT", raising=False)
-    for x, y in zip(*out):
-        assert np.array_equal(x, y)
+    monkeypatch.delenv("T4D_PH_THREADS", raising=False)
+    monkeypatch.delenv("T4D_PH_ROWS", raising=False)
+    for o in out[1:]:
+        assert np.array_equal(o[1], out[0][1])
+        assert np.abs(o[0] - out[0][0]).max() < 1e-6
+        for x, y in zip(o[2:], out[0][2:]):
+            assert np.abs(x - y).max() <= 1e-5 * np.abs(y).max()
     assert np.isfinite(out[0][0]).all() and np.abs(out[0][1]).max() > 0

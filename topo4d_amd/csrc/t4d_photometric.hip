@@ -7,11 +7,11 @@
 // SSIM: depthwise 11x11 Gaussian window (sigma 1.5), zero padding, c1 = 0.01^2, c2 = 0.03^2.
 // The reference spends 5 conv2d launches forward and their autograd backward per iteration; here one launch set per
 // batch of V views produces the per-view losses AND dL/d(im) (the rasterizer's backward input) AND dL/d(cam_m, cam_c):
-//   k_photo_stats   per (view, channel, 16x16 tile): stage im', gt with a 5-px halo in LDS, separable 11-tap filter of
-//                   (x, y, x^2, y^2, xy), SSIM map + L1 term -> partial loss sums, and the three adjoint maps
-//                   D1 = g*dS/dmu1, D2 = g*dS/dE[x^2], D3 = g*dS/dE[xy]
-//   k_photo_grad    per tile: separable filter of D1, D2, D3 (the window is symmetric: adjoint = same filter),
-//                   dL/dx' = G*D1 + 2x'(G*D2) + y(G*D3) + L1 term; affine backward; partial sums for cam_m / cam_c
+//   k_photo_stream  one workgroup per (view, channel, strip of columns, segment of rows) streams down its strip: separable
+//                   11-tap filter of (x, y, x^2 + y^2, x y), SSIM + L1 -> partial loss sums and the three adjoint values
+//                   D1 = g dS/dmu1, D2 = g dS/dE[x^2], D3 = g dS/dE[xy] of the row five behind; separable filter of those
+//                   (the window is symmetric: adjoint = same filter) -> dL/dx' = G*D1 + 2x'(G*D2) + y(G*D3) + L1 term of
+//                   the row eleven behind; affine backward; partial sums for cam_m / cam_c.  No intermediate in memory.
 //   k_photo_final   fixed-order sums of the partials (deterministic)
 // Pinned by tests against topo4d_amd/loss.py, itself pinned by golden G3 captured from the real reference functions.
 #include <hip/hip_runtime.h>
@@ -26,23 +26,7 @@ int t4d_internal_fail(int code, const char *fmt, const char *a);
 
 namespace {
 
-// One kernel, no intermediate in memory.  (Rounds 1-2 ran two tile kernels with the three adjoint maps going through HBM in
-// between: 302 MB written and - with the halo - 570 MB read back per 24 x 512^2 views, 0.46 ms of kernels against a traffic
-// floor of ~0.1 ms.)  A workgroup of 128 threads owns a vertical STRIP of one channel of one view - up to 118 output columns, a
-// segment of rows - and streams down it one image row per iteration; every thread owns ONE column:
-//   * the row's (x', gt) go to LDS; each thread takes the 11-tap HORIZONTAL sums of (x, y, x^2, y^2, xy) at its column and
-//     pushes them into a window of the last eleven rows that lives in REGISTERS; the VERTICAL sums over that window are the
-//     five filtered maps at the row five behind - SSIM, loss terms and the three adjoint values D1..D3 of that pixel;
-//   * the adjoint row goes to LDS (its columns reach five beyond the strip on either side, which is why a strip of 118 uses
-//     128 threads); each thread takes its horizontal 11-tap sums, pushes them into a second register window, and the
-//     vertical sums over it give G*D1, G*D2, G*D3 at the row five further behind: dL/dx' and the affine backward.
-// Both 2-D windows are separable and symmetric, so adjoint = same filter.  Rows are unrolled eleven at a time so that the
-// window slots are compile-time register names (no shifting).  One barrier per row; the only redundancy is the warm-up of a
-// segment (20 rows) and the 10 halo columns of a strip.
 constexpr int kR = 5;              // window radius (11 taps)
-// threads per workgroup = columns of the first stage = output columns of a strip + 10: the launch picks the instantiation
-// (64, 128, 192 or 256 threads) that covers the image width with the fewest thread-columns (512 wide: 3 strips of 171 columns
-// on 192 threads; 375 wide: 7 strips of 54 on 64 threads)
 constexpr int kBlock = 256;        // (k_photo_final and the masked-L1 kernels)
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
@@ -70,27 +54,49 @@ __device__ __forceinline__ float block_sum(float v, float *s_red)
 }
 
 template <int N> struct IC { static constexpr int value = N; };
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));      // packed-math pair: one v_pk_fma_f32 does two of the filter's multiply-adds
 
-#ifndef T4D_PH_WAVES
-#define T4D_PH_WAVES 3             // 166 registers: three waves per SIMD (four = 128 registers spills in the row loop: 258 -> 427 us)
-#endif
+// The strip kernel.  A workgroup of kFT threads owns a vertical STRIP of one channel of one view - kFT input columns, hence
+// kFT - 10 first-stage columns and kFT - 20 output columns - and a segment of rows, and streams down it one image row per
+// iteration; every thread owns ONE column of each stage:
+//   * the thread that loads a pixel forms (x', y, s = x'^2 + y^2, p = x' y) ONCE and writes them to LDS as one 16-byte entry;
+//     a thread's 11-tap HORIZONTAL sums of the four maps are eleven ds_read_b128 and twenty-two v_pk_fma_f32.  (SSIM needs
+//     E[x^2] and E[y^2] only as their sum: B2 = E[x^2] + E[y^2] - mu1^2 - mu2^2 + c2, so four maps suffice where round 3
+//     filtered five and squared every pixel once per tap.)  The sums go into a window of the last eleven rows that lives in
+//     REGISTERS; the VERTICAL sums over it are the filtered maps at the row five behind - SSIM, loss terms and the three
+//     adjoint values of that pixel, one reciprocal (+ a Newton step) per pixel;
+//   * the adjoint row goes to LDS; each thread takes its horizontal sums, pushes them into a second register window, and the
+//     vertical sums over that give G*D1, G*D2, G*D3 at the row five further behind: dL/dx' and the affine backward.  The
+//     output pixel is fetched again (an L2 hit) rather than carried through eleven iterations.
+// Rows are unrolled eleven at a time so that the window slots are compile-time register names (no shifting).  One barrier per
+// row; no other branch in the row body than two wave-uniform row tests: loads use clamped addresses through buffer
+// descriptors (column offset in a loop-invariant register, row offset in a scalar: no vector address arithmetic), validity
+// is a select, columns that belong to a neighbouring strip are computed and dropped from the sums at the very end.
+// 123 registers: four waves per SIMD.  Round 3's kernel (five maps, (x', y) pairs in LDS, IEEE division, 25 branches per
+// row: ~250 vector instructions per thread and row) -> ~160: 24 x 512^2 224 -> 180 us, 24 x 2048^2 2.95 -> 2.29 ms.  What it is
+// bound by (ablation builds, tools/experiments/README.md): without its LDS reads and barriers it still takes 162 us - the
+// vector ALUs of the busiest CUs (864 workgroups on 256 CUs: four on some, three on others).
 template <int kFT>
-__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_WAVES, T4D_PH_WAVES))) void k_photo_fused(const PhP P)
+__global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_photo_stream(const PhP P)
 {
-    constexpr int kInW = kFT + 2 * kR;                   // input columns a row needs: 138
-    __shared__ float2 s_in[2][kInW];                     // (x', gt) of the current row, zero padded
-    // adjoint row (D1, D2 | D3) at the first stage's columns (+ slack: the last ten threads of the second stage read beyond them
-    // and emit nothing)
-    __shared__ float2 s_d01[2][kFT + 2 * kR + 2];
-    __shared__ float s_d2[2][kFT + 2 * kR + 2];
+    constexpr int kRow = kFT + 16;                        // entries per LDS row: kFT + the ten a last thread reads beyond
+    __shared__ v4f s_in[2][kRow];                         // (x', y, x'^2 + y^2, x' y) of the current input row
+    __shared__ v4f s_d[2][kRow];                          // (D1, D2, D3, -) of the current adjoint row
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int vc = blockIdx.z, v = vc / 3;
     const int xs = blockIdx.x * P.tw, xe = min(xs + P.tw, P.W);              // output columns [xs, xe)
     const int y0 = blockIdx.y * P.th, y1 = min(y0 + P.th, P.H);              // output rows [y0, y1)
     const size_t HW = (size_t)P.H * P.W;
-    const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
+    // one buffer descriptor per plane: a load is `buffer_load_dword v, v_col4, s[rsrc], s_row_offset offen`
+    const unsigned plane_bytes = (unsigned)(HW * 4);
+    const __amdgpu_buffer_rsrc_t r_im = __builtin_amdgcn_make_buffer_rsrc((void *)(P.im + (size_t)vc * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_gt = __builtin_amdgcn_make_buffer_rsrc((void *)(P.gt + (size_t)vc * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void *)(P.dL_dim + (size_t)vc * HW), 0, plane_bytes, 0x00020000);
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
     const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
     const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
     const float g = -0.2f * wv / N;                      // dL/dS
@@ -99,115 +105,108 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_WAVE
 #pragma unroll
     for (int k = 0; k < 11; k++) w[k] = P.win[k];
 
-    const int gx1 = xs - kR + tid;                       // this thread's column in the first stage
-    const bool col1 = gx1 >= 0 && gx1 < P.W;
-    const bool own1 = tid >= kR && gx1 < xe;             // ... which belongs to this strip's outputs (loss terms are counted once)
-    const int gx2 = xs + tid;                            // ... and in the second stage
-    const bool col2 = gx2 < xe;
-    // columns this thread loads of every input row: xs - 10 + tid and (the first ten threads) 128 further right
-    const int lx0 = xs - 2 * kR + tid, lx1 = lx0 + kFT;
-    const bool l0 = lx0 >= 0 && lx0 < P.W, l1 = tid < 2 * kR && lx1 < P.W;
-
-    // the two register windows (slots are compile-time indices); pairs of maps share a 64-bit register pair so that the
-    // vertical sums run as packed multiply-adds: (x, y), (x^2, y^2) | xy  and  (D1, D2) | D3
+    // this thread's input column, first-stage column and output column
+    const int gin = xs - 2 * kR + tid, g1 = xs - kR + tid, g2 = xs + tid;
+    const bool in_col = gin >= 0 && gin < P.W;
+    const bool col1 = g1 >= 0 && g1 < P.W;               // the adjoint map exists inside the image only
+    const bool own1 = g1 >= xs && g1 < xe;               // ... and this strip counts its SSIM term
+    const bool col2 = g2 < xe;                           // an output column of this strip
+    const unsigned off_in = 4u * (unsigned)min(max(gin, 0), P.W - 1), off_out = 4u * (unsigned)min(g2, P.W - 1);
+    // zero both buffers once (the entries beyond the strip's columns stay zero)
+    for (int e = tid; e < kRow; e += kFT) {
+        s_in[0][e] = s_in[1][e] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+        s_d[0][e] = s_d[1][e] = (v4f){ 0.f, 0.f, 0.f, 0.f };
+    }
+    // the two register windows (slots are compile-time indices): (x, y), (s, p) and (D1, D2) | D3
     v2f h01[11], h23[11], hd01[11];
-    float h4[11], hd2[11];
+    float hd2[11];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         h01[k] = h23[k] = hd01[k] = (v2f){ 0.f, 0.f };
-        h4[k] = hd2[k] = 0.f;
+        hd2[k] = 0.f;
     }
-    for (int b = 0; b < 2; b++) {                        // the first iteration's second stage reads a row nobody wrote
-        s_d01[b][tid] = make_float2(0.f, 0.f); s_d2[b][tid] = 0.f;
-        if (tid < 2 * kR + 2) { s_d01[b][kFT + tid] = make_float2(0.f, 0.f); s_d2[b][kFT + tid] = 0.f; }
-    }
+    // partial sums: rows are gated by wave-uniform tests inside the loop, this thread's columns once at the end
     float sum_l1 = 0.f, sum_s = 0.f, sum_gm = 0.f, sum_gc = 0.f;
-    const int i_first = y0 - 2 * kR, i_last = y1 + 2 * kR;      // input rows i_first .. i_last (the last one only drains)
+    const int i_first = y0 - 2 * kR, i_last = y1 + 2 * kR;      // input rows i_first .. i_last (the last ones only drain)
 
-    // prefetch of the first row
-    float pa0 = 0.f, pb0 = 0.f, pa1 = 0.f, pb1 = 0.f;
+    float pa, pb;                                        // the next row's pixel, in flight
     auto fetch = [&](int i) {
-        pa0 = pb0 = pa1 = pb1 = 0.f;
-        if (i >= 0 && i < P.H) {
-            const size_t o = (size_t)i * P.W;
-            if (l0) { pa0 = im[o + lx0]; pb0 = gt[o + lx0]; }
-            if (l1) { pa1 = im[o + lx1]; pb1 = gt[o + lx1]; }
-        }
+        const unsigned ro = (unsigned)min(max(i, 0), P.H - 1) * (unsigned)P.W * 4u;
+        pa = ldf(r_im, off_in, ro); pb = ldf(r_gt, off_in, ro);
     };
     fetch(i_first);
+    __syncthreads();
 
     auto row = [&](const int i, auto J_) {
-        constexpr int J = decltype(J_)::value;           // slot of this row in both windows
+        constexpr int J = decltype(J_)::value;           // slot of this row in the first window
         const int buf = i & 1;
-        // ---- this row's inputs to LDS (zero padding outside the image: external.py:86 padding=5), next row's loads in flight
+        // ---- this row's inputs to LDS, zero outside the image (external.py:86 padding=5); next row's loads in flight
         {
-            const bool in_img = i >= 0 && i < P.H;
-            s_in[buf][tid] = (in_img && l0) ? make_float2(em * pa0 + cc, pb0) : make_float2(0.f, 0.f);
-            if (tid < 2 * kR) s_in[buf][tid + kFT] = (in_img && l1) ? make_float2(em * pa1 + cc, pb1) : make_float2(0.f, 0.f);
+            const bool ok = (unsigned)i < (unsigned)P.H && in_col;
+            const float x = ok ? fmaf(em, pa, cc) : 0.f, y = ok ? pb : 0.f;
+            s_in[buf][tid] = (v4f){ x, y, fmaf(x, x, y * y), x * y };
         }
         fetch(i + 1);
-        // the pixel of the OUTPUT row of this iteration (eleven rows behind): needed at the very end, requested now
+        // the pixel of this iteration's OUTPUT row (eleven rows behind): needed at the very end, requested now
         const int o_row = i - 2 * kR - 1;
-        const bool emit = col2 && o_row >= y0 && o_row < y1;
-        float o_im = 0.f, o_gt = 0.f;
-        if (emit) { o_im = im[(size_t)o_row * P.W + gx2]; o_gt = gt[(size_t)o_row * P.W + gx2]; }
-#ifndef T4D_PH_NOBARRIER          // (timing experiment: what the one barrier per row costs; results are wrong without it)
+        const bool o_ok = o_row >= y0 && o_row < y1;
+        const unsigned oro = (unsigned)min(max(o_row, 0), P.H - 1) * (unsigned)P.W * 4u;
+        const float o_im = ldf(r_im, off_out, oro), o_gt = ldf(r_gt, off_out, oro);
         __syncthreads();
-#endif
-        // ---- first stage, horizontal: 11 taps of (x, y, x^2, y^2, xy) at this thread's column
+        // ---- first stage, horizontal
         {
             v2f a01 = { 0.f, 0.f }, a23 = { 0.f, 0.f };
-            float a4 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                const v2f ab = *reinterpret_cast<const v2f *>(&s_in[buf][tid + k]);
-                const v2f wab = w[k] * ab;                       // four instructions per tap for the five sums
-                a01 += wab;
-                a23 = __builtin_elementwise_fma(wab, ab, a23);
-                a4 = fmaf(wab.x, ab.y, a4);
+                const v4f q = s_in[buf][tid + k];
+                const v2f wk = { w[k], w[k] };
+                a01 = __builtin_elementwise_fma(wk, (v2f){ q.x, q.y }, a01);
+                a23 = __builtin_elementwise_fma(wk, (v2f){ q.z, q.w }, a23);
             }
-            h01[J] = a01; h23[J] = a23; h4[J] = a4;
+            h01[J] = a01; h23[J] = a23;
         }
-        // ---- first stage, vertical: rows i-10 .. i are in slots J+1 .. J+11 (mod 11) -> the filtered maps at row s = i - 5
+        // ---- first stage, vertical: rows i-10 .. i are in slots J+1 .. J+11 (mod 11) -> the filtered maps at row i - 5
         {
-            v2f m12 = { 0.f, 0.f }, eac = { 0.f, 0.f };
-            float eb = 0.f;
+            v2f m12 = { 0.f, 0.f }, esp = { 0.f, 0.f };
 #pragma unroll
             for (int k = 0; k < 11; k++) {
                 const int sl = (J + 1 + k) % 11;
                 const v2f wk = { w[k], w[k] };
                 m12 = __builtin_elementwise_fma(wk, h01[sl], m12);
-                eac = __builtin_elementwise_fma(wk, h23[sl], eac);
-                eb = fmaf(w[k], h4[sl], eb);
+                esp = __builtin_elementwise_fma(wk, h23[sl], esp);
             }
-            const float mu1 = m12.x, mu2 = m12.y, ea = eac.x, ec = eac.y;
+            // S = A1 A2 / (B1 B2),  s11 + s22 = E[x^2 + y^2] - mu1^2 - mu2^2,  s12 = E[xy] - mu1 mu2
+            const float mu1 = m12.x, mu2 = m12.y, es = esp.x, ep = esp.y;
+            const float mu12 = mu1 * mu2;
+            const float B1 = fmaf(mu1, mu1, fmaf(mu2, mu2, kC1));
+            const float B2 = (es - B1) + (kC1 + kC2);
+            const float A1 = fmaf(2.f, mu12, kC1), A2 = fmaf(2.f, ep - mu12, kC2);
+            const float den = B1 * B2;
+            float inv = __builtin_amdgcn_rcpf(den);              // the one reciprocal of the pixel: 1/B1 = B2 inv, 1/B2 = B1 inv
+            inv = fmaf(fmaf(-den, inv, 1.f), inv, inv);
+            const float S = A1 * A2 * inv;
             const int srow = i - kR;
-            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
-            if (col1 && srow >= 0 && srow < P.H) {               // the adjoint map exists inside the image only
-                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s11 = ea - mu1s, s22 = ec - mu2s, s12 = eb - mu12;
-                const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
-                const float inv = 1.f / (B1 * B2);               // the one division of the pixel: 1/B1 = B2 * inv, 1/B2 = B1 * inv
-                const float S = A1 * A2 * inv;
-                // S = A1 A2 / (B1 B2) with s11 = a - mu1^2, s12 = b - mu1 mu2 (a, b, c = filtered x^2, xy, y^2)
-                const float gi = g * inv;
-                d1 = 2.f * gi * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
-                d2 = -gi * S * B1;
-                d3 = 2.f * gi * A1;
-                if (own1 && srow >= y0 && srow < y1) sum_s += S;
-            }
-            s_d01[buf][tid] = make_float2(d1, d2); s_d2[buf][tid] = d3;
+            const float gi = ((unsigned)srow < (unsigned)P.H && col1) ? g * inv : 0.f;
+            const float gi2 = gi + gi;
+            const float d1 = gi2 * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
+            const float d2 = -gi * S * B1, d3 = gi2 * A1;
+            s_d[buf][tid] = (v4f){ d1, d2, d3, 0.f };
+            if (srow >= y0 && srow < y1) sum_s += S;     // wave-uniform
         }
         // ---- second stage on the adjoint row written ONE iteration ago (made visible by this iteration's barrier)
         {
-            const int pb = buf ^ 1;
+            const int pb_ = buf ^ 1;
             v2f q01 = { 0.f, 0.f };
             float q2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
+                // (the empty asm keeps the compiler from narrowing the read to the three values used: ds_read_b96 runs at
+                // 96 B/clk, ds_read_b128 at 256)
+                v4f q = s_d[pb_][tid + k];
+                asm("" : "+v"(q));
                 const v2f wk = { w[k], w[k] };
-                q01 = __builtin_elementwise_fma(wk, *reinterpret_cast<const v2f *>(&s_d01[pb][tid + k]), q01);
-                q2 = fmaf(w[k], s_d2[pb][tid + k], q2);
+                q01 = __builtin_elementwise_fma(wk, (v2f){ q.x, q.y }, q01);
+                q2 = fmaf(w[k], q.z, q2);
             }
             constexpr int J2 = (J + 10) % 11;            // the adjoint row of the previous iteration sits one slot back
             hd01[J2] = q01; hd2[J2] = q2;
@@ -220,15 +219,15 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_WAVE
                 r01 = __builtin_elementwise_fma(wk, hd01[sl], r01);
                 r2 = fmaf(w[k], hd2[sl], r2);
             }
-            const float r0 = r01.x, r1 = r01.y;
-            if (emit) {
-                const float x = em * o_im + cc, y = o_gt;
+            if (o_ok) {                                  // wave-uniform: an output row of this segment
+                const float xi = em * o_im;
+                const float x = fmaf(em, o_im, cc), y = o_gt;
                 const float d = x - y;
+                const float gl1 = d == 0.f ? 0.f : copysignf(l1w, d);                        // 0.8 / N * sign(x' - y)
+                const float gg = fmaf(x + x, r01.y, r01.x) + fmaf(y, r2, gl1);               // dL/dx'
+                if (col2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, em * gg), r_out, off_out, oro, 0);
                 sum_l1 += fabsf(d);
-                const float gl1 = l1w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-                const float gg = r0 + 2.f * x * r1 + y * r2 + gl1;                   // dL/dx'
-                P.dL_dim[(size_t)vc * HW + (size_t)o_row * P.W + gx2] = em * gg;
-                sum_gm += gg * (em * o_im);                                          // d x'/d cam_m = exp(cam_m) * im
+                sum_gm = fmaf(gg, xi, sum_gm);           // d x'/d cam_m = exp(cam_m) * im
                 sum_gc += gg;
             }
         }
@@ -241,198 +240,9 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_WAVE
         if (base + 8 <= i_last) row(base + 8, IC<8>()); if (base + 9 <= i_last) row(base + 9, IC<9>());
         if (base + 10 <= i_last) row(base + 10, IC<10>());
     }
-    const float tl1 = block_sum(sum_l1, s_red), tss = block_sum(sum_s, s_red);
-    const float tgm = block_sum(sum_gm, s_red), tgc = block_sum(sum_gc, s_red);
+    const float tl1 = block_sum(col2 ? sum_l1 : 0.f, s_red), tss = block_sum(own1 ? sum_s : 0.f, s_red);
+    const float tgm = block_sum(col2 ? sum_gm : 0.f, s_red), tgc = block_sum(col2 ? sum_gc : 0.f, s_red);
     if (tid == 0) {
-        const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
-        P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
-        P.part_cam[2 * t] = tgm; P.part_cam[2 * t + 1] = tgc;
-    }
-}
-
-// The same strip, two WAVE ROLES (round 3): threads [0, kFT) run the first stage - inputs, the five filtered maps, SSIM, the
-// adjoint row - and threads [kFT, 2 kFT) the second - the three filtered adjoint maps, dL/dx', the affine backward.  One
-// thread per column held both register windows (55 + 33 values) and their arithmetic: 166 registers, three waves per SIMD,
-// and at 24 x 512^2 only 2,592 waves for 1,024 SIMDs - the vector ALUs were busy 57 % of the kernel (rocprofv3 PMC: 78 M
-// instructions = 128 us of issue in a 237 us kernel; the rest is a wave waiting for its own LDS round trips and barrier).
-// Split by stage a thread needs ~100 / ~70 registers and there are twice as many waves.  The arithmetic, its order and the
-// one barrier per row are unchanged: results are bit-identical to k_photo_fused.  Measured (see the launch below): it pays for
-// a single view, not for a batch - the two stages wait for each other at the row barrier and the first is twice the second.
-#ifndef T4D_PH_SPLIT_WAVES
-#define T4D_PH_SPLIT_WAVES 4
-#endif
-template <int kFT>
-__global__ __launch_bounds__(2 * kFT) __attribute__((amdgpu_waves_per_eu(T4D_PH_SPLIT_WAVES, T4D_PH_SPLIT_WAVES))) void k_photo_split(const PhP P)
-{
-    constexpr int kInW = kFT + 2 * kR;
-    __shared__ float2 s_in[2][kInW];
-    __shared__ float2 s_d01[2][kFT + 2 * kR + 2];
-    __shared__ float s_d2[2][kFT + 2 * kR + 2];
-    __shared__ float s_red[8];
-    const bool first = threadIdx.x < kFT;                // wave-uniform: kFT is a multiple of 64
-    const int tid = first ? threadIdx.x : threadIdx.x - kFT;
-    const int vc = blockIdx.z, v = vc / 3;
-    const int xs = blockIdx.x * P.tw, xe = min(xs + P.tw, P.W);
-    const int y0 = blockIdx.y * P.th, y1 = min(y0 + P.th, P.H);
-    const size_t HW = (size_t)P.H * P.W;
-    const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
-    const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
-    const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
-    const float g = -0.2f * wv / N;
-    const float l1w = 0.8f * wv / N;
-    float w[11];
-#pragma unroll
-    for (int k = 0; k < 11; k++) w[k] = P.win[k];
-    for (int b = 0; b < 2; b++) {                        // the first iteration's second stage reads a row nobody wrote
-        if (first) {
-            s_d01[b][tid] = make_float2(0.f, 0.f); s_d2[b][tid] = 0.f;
-            if (tid < 2 * kR + 2) { s_d01[b][kFT + tid] = make_float2(0.f, 0.f); s_d2[b][kFT + tid] = 0.f; }
-        }
-    }
-    const int i_first = y0 - 2 * kR, i_last = y1 + 2 * kR;
-    float sum_l1 = 0.f, sum_s = 0.f, sum_gm = 0.f, sum_gc = 0.f;
-
-    if (first) {
-        // ---------------- first stage ----------------
-        const int gx1 = xs - kR + tid;
-        const bool col1 = gx1 >= 0 && gx1 < P.W;
-        const bool own1 = tid >= kR && gx1 < xe;
-        const int lx0 = xs - 2 * kR + tid, lx1 = lx0 + kFT;
-        const bool l0 = lx0 >= 0 && lx0 < P.W, l1 = tid < 2 * kR && lx1 < P.W;
-        v2f h01[11], h23[11];
-        float h4[11];
-#pragma unroll
-        for (int k = 0; k < 11; k++) { h01[k] = h23[k] = (v2f){ 0.f, 0.f }; h4[k] = 0.f; }
-        float pa0 = 0.f, pb0 = 0.f, pa1 = 0.f, pb1 = 0.f;
-        auto fetch = [&](int i) {
-            pa0 = pb0 = pa1 = pb1 = 0.f;
-            if (i >= 0 && i < P.H) {
-                const size_t o = (size_t)i * P.W;
-                if (l0) { pa0 = im[o + lx0]; pb0 = gt[o + lx0]; }
-                if (l1) { pa1 = im[o + lx1]; pb1 = gt[o + lx1]; }
-            }
-        };
-        fetch(i_first);
-        auto row = [&](const int i, auto J_) {
-            constexpr int J = decltype(J_)::value;
-            const int buf = i & 1;
-            {
-                const bool in_img = i >= 0 && i < P.H;
-                s_in[buf][tid] = (in_img && l0) ? make_float2(em * pa0 + cc, pb0) : make_float2(0.f, 0.f);
-                if (tid < 2 * kR) s_in[buf][tid + kFT] = (in_img && l1) ? make_float2(em * pa1 + cc, pb1) : make_float2(0.f, 0.f);
-            }
-            fetch(i + 1);
-            __syncthreads();
-            {
-                v2f a01 = { 0.f, 0.f }, a23 = { 0.f, 0.f };
-                float a4 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) {
-                    const v2f ab = *reinterpret_cast<const v2f *>(&s_in[buf][tid + k]);
-                    const v2f wab = w[k] * ab;
-                    a01 += wab;
-                    a23 = __builtin_elementwise_fma(wab, ab, a23);
-                    a4 = fmaf(wab.x, ab.y, a4);
-                }
-                h01[J] = a01; h23[J] = a23; h4[J] = a4;
-            }
-            v2f m12 = { 0.f, 0.f }, eac = { 0.f, 0.f };
-            float eb = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const int sl = (J + 1 + k) % 11;
-                const v2f wk = { w[k], w[k] };
-                m12 = __builtin_elementwise_fma(wk, h01[sl], m12);
-                eac = __builtin_elementwise_fma(wk, h23[sl], eac);
-                eb = fmaf(w[k], h4[sl], eb);
-            }
-            const float mu1 = m12.x, mu2 = m12.y, ea = eac.x, ec = eac.y;
-            const int srow = i - kR;
-            float d1 = 0.f, d2 = 0.f, d3 = 0.f;
-            if (col1 && srow >= 0 && srow < P.H) {
-                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s11 = ea - mu1s, s22 = ec - mu2s, s12 = eb - mu12;
-                const float A1 = 2.f * mu12 + kC1, A2 = 2.f * s12 + kC2, B1 = mu1s + mu2s + kC1, B2 = s11 + s22 + kC2;
-                const float inv = 1.f / (B1 * B2);
-                const float S = A1 * A2 * inv;
-                const float gi = g * inv;
-                d1 = 2.f * gi * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
-                d2 = -gi * S * B1;
-                d3 = 2.f * gi * A1;
-                if (own1 && srow >= y0 && srow < y1) sum_s += S;
-            }
-            s_d01[buf][tid] = make_float2(d1, d2); s_d2[buf][tid] = d3;
-        };
-        for (int base = i_first; base <= i_last; base += 11) {
-            if (base + 0 <= i_last) row(base + 0, IC<0>()); if (base + 1 <= i_last) row(base + 1, IC<1>());
-            if (base + 2 <= i_last) row(base + 2, IC<2>()); if (base + 3 <= i_last) row(base + 3, IC<3>());
-            if (base + 4 <= i_last) row(base + 4, IC<4>()); if (base + 5 <= i_last) row(base + 5, IC<5>());
-            if (base + 6 <= i_last) row(base + 6, IC<6>()); if (base + 7 <= i_last) row(base + 7, IC<7>());
-            if (base + 8 <= i_last) row(base + 8, IC<8>()); if (base + 9 <= i_last) row(base + 9, IC<9>());
-            if (base + 10 <= i_last) row(base + 10, IC<10>());
-        }
-    } else {
-        // ---------------- second stage ----------------
-        const int gx2 = xs + tid;
-        const bool col2 = gx2 < xe;
-        v2f hd01[11];
-        float hd2[11];
-#pragma unroll
-        for (int k = 0; k < 11; k++) { hd01[k] = (v2f){ 0.f, 0.f }; hd2[k] = 0.f; }
-        auto row = [&](const int i, auto J_) {
-            constexpr int J = decltype(J_)::value;
-            const int buf = i & 1;
-            // the pixel of the OUTPUT row of this iteration (eleven rows behind): needed at the very end, requested now
-            const int o_row = i - 2 * kR - 1;
-            const bool emit = col2 && o_row >= y0 && o_row < y1;
-            float o_im = 0.f, o_gt = 0.f;
-            if (emit) { o_im = im[(size_t)o_row * P.W + gx2]; o_gt = gt[(size_t)o_row * P.W + gx2]; }
-            __syncthreads();
-            // the adjoint row written ONE iteration ago by the first stage (made visible by this iteration's barrier)
-            const int pb = buf ^ 1;
-            v2f q01 = { 0.f, 0.f };
-            float q2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const v2f wk = { w[k], w[k] };
-                q01 = __builtin_elementwise_fma(wk, *reinterpret_cast<const v2f *>(&s_d01[pb][tid + k]), q01);
-                q2 = fmaf(w[k], s_d2[pb][tid + k], q2);
-            }
-            constexpr int J2 = (J + 10) % 11;
-            hd01[J2] = q01; hd2[J2] = q2;
-            v2f r01 = { 0.f, 0.f };
-            float r2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const int sl = (J2 + 1 + k) % 11;
-                const v2f wk = { w[k], w[k] };
-                r01 = __builtin_elementwise_fma(wk, hd01[sl], r01);
-                r2 = fmaf(w[k], hd2[sl], r2);
-            }
-            const float r0 = r01.x, r1 = r01.y;
-            if (emit) {
-                const float x = em * o_im + cc, y = o_gt;
-                const float d = x - y;
-                sum_l1 += fabsf(d);
-                const float gl1 = l1w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-                const float gg = r0 + 2.f * x * r1 + y * r2 + gl1;
-                P.dL_dim[(size_t)vc * HW + (size_t)o_row * P.W + gx2] = em * gg;
-                sum_gm += gg * (em * o_im);
-                sum_gc += gg;
-            }
-        };
-        for (int base = i_first; base <= i_last; base += 11) {
-            if (base + 0 <= i_last) row(base + 0, IC<0>()); if (base + 1 <= i_last) row(base + 1, IC<1>());
-            if (base + 2 <= i_last) row(base + 2, IC<2>()); if (base + 3 <= i_last) row(base + 3, IC<3>());
-            if (base + 4 <= i_last) row(base + 4, IC<4>()); if (base + 5 <= i_last) row(base + 5, IC<5>());
-            if (base + 6 <= i_last) row(base + 6, IC<6>()); if (base + 7 <= i_last) row(base + 7, IC<7>());
-            if (base + 8 <= i_last) row(base + 8, IC<8>()); if (base + 9 <= i_last) row(base + 9, IC<9>());
-            if (base + 10 <= i_last) row(base + 10, IC<10>());
-        }
-    }
-    const float tl1 = block_sum(sum_l1, s_red), tss = block_sum(sum_s, s_red);
-    const float tgm = block_sum(sum_gm, s_red), tgc = block_sum(sum_gc, s_red);
-    if (threadIdx.x == 0) {
         const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
         P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
         P.part_cam[2 * t] = tgm; P.part_cam[2 * t + 1] = tgc;
@@ -561,23 +371,26 @@ T4D_EXPORT int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const f
     return T4D_OK;
 }
 
-// strips and row segments of the fused kernel for an H x W image: strips as even as possible; segments of 128 rows from 16 M
-// values per batch on, 64 from 2 M, 16 below (one view of Topo4D's 512 x 375 images: more, shorter workgroups - every segment
-// pays 21 warm-up rows, but a lone view is latency-bound)
+// strips and row segments for an H x W image.  A strip of kFT threads yields kFT - 20 output columns: the launch picks the
+// instantiation (64, 128, 192 or 256 threads) that covers the image width with the fewest thread-columns (512 wide: 3 strips
+// of 171 columns on 192 threads; ties go to the wider strip).  Segments of 128 rows from 16 M values per batch on, 64 from
+// 2 M, 16 below (one view of Topo4D's 512 x 375 images: more, shorter workgroups of a single wave - every segment pays 21
+// warm-up rows, but a lone view is latency-bound).  T4D_PH_THREADS / T4D_PH_ROWS override (sweeps: tools/sweep_loss_kernels.py).
 static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty, int *tw, int *th, int *threads)
 {
+    const long long work = (long long)n_views * 3 * H * W;
     int best = 0;
     long long best_cost = 0;
     for (int ft = 64; ft <= 256; ft += 64) {
-        const int strips = (W + (ft - 2 * kR) - 1) / (ft - 2 * kR);
+        const int strips = (W + (ft - 4 * kR) - 1) / (ft - 4 * kR);
         const long long cost = (long long)strips * ft;
-        if (best == 0 || cost < best_cost) { best = ft; best_cost = cost; }
+        if (best == 0 || cost <= best_cost) { best = ft; best_cost = cost; }
     }
+    if (work < (1ll << 20)) best = 64;
     if (const char *e = getenv("T4D_PH_THREADS")) { const int ft = atoi(e); if (ft == 64 || ft == 128 || ft == 192 || ft == 256) best = ft; }
     *threads = best;
-    *tx = (W + (best - 2 * kR) - 1) / (best - 2 * kR);
+    *tx = (W + (best - 4 * kR) - 1) / (best - 4 * kR);
     *tw = (W + *tx - 1) / *tx;
-    const long long work = (long long)n_views * 3 * H * W;
     *th = work >= (1ll << 24) ? 128 : (work >= (1ll << 21) ? 64 : 16);
     if (const char *e = getenv("T4D_PH_ROWS")) *th = atoi(e) > 0 ? atoi(e) : *th;      // experiments
     if (*th > H) *th = H;
@@ -610,6 +423,7 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     int ft = 0;
     photo_tiling(n_views, H, W, &P.tx, &P.ty, &P.tw, &P.th, &ft);
     if (P.ty > 65535) return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: image too tall%s", "");
+    if ((size_t)H * W > ((size_t)1 << 30)) return t4d_internal_fail(T4D_ERR_ARG, "t4d_photometric_loss: more than 2^30 pixels per plane%s", "");
     P.im = im; P.gt = gt; P.cam_m = cam_m; P.cam_c = cam_c; P.weight = view_weight;
     P.loss = loss; P.dL_dim = dL_dim; P.dL_dm = dL_dcam_m; P.dL_dc = dL_dcam_c;
     const size_t tiles = (size_t)P.tx * P.ty * n_views * 3;
@@ -622,21 +436,10 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     for (int i = 0; i < 11; i++) P.win[i] = g[i] / sum;
     hipStream_t stream = (hipStream_t)hip_stream;
     const dim3 grid(P.tx, P.ty, n_views * 3);
-    // Two wave roles per strip (k_photo_split) for ONE view's worth of pixels - a launch that cannot fill the chip, where the
-    // second set of waves shortens every workgroup's row: 36.5 -> 29.7 us for a 512 x 375 view.  A batch of views keeps one
-    // thread per column for both stages: there the roles only add waves that wait for each other at the row barrier (the first
-    // stage is twice the second: 24 x 512^2 235 -> 258-330 us, 24 x 2048^2 -2 %).  T4D_PH_SPLIT=0/1 forces one or the other.
-    const char *split_env = getenv("T4D_PH_SPLIT");
-    const bool split = split_env ? atoi(split_env) != 0 : (long long)n_views * 3 * H * W < (1ll << 21);
-    if (split) {
-        if (ft == 64) hipLaunchKernelGGL(k_photo_split<64>, grid, dim3(128), 0, stream, P);
-        else if (ft == 128) hipLaunchKernelGGL(k_photo_split<128>, grid, dim3(256), 0, stream, P);
-        else if (ft == 192) hipLaunchKernelGGL(k_photo_split<192>, grid, dim3(384), 0, stream, P);
-        else hipLaunchKernelGGL(k_photo_split<256>, grid, dim3(512), 0, stream, P);
-    } else if (ft == 64) hipLaunchKernelGGL(k_photo_fused<64>, grid, dim3(64), 0, stream, P);
-    else if (ft == 128) hipLaunchKernelGGL(k_photo_fused<128>, grid, dim3(128), 0, stream, P);
-    else if (ft == 192) hipLaunchKernelGGL(k_photo_fused<192>, grid, dim3(192), 0, stream, P);
-    else hipLaunchKernelGGL(k_photo_fused<256>, grid, dim3(256), 0, stream, P);
+    if (ft == 64) hipLaunchKernelGGL(k_photo_stream<64>, grid, dim3(64), 0, stream, P);
+    else if (ft == 128) hipLaunchKernelGGL(k_photo_stream<128>, grid, dim3(128), 0, stream, P);
+    else if (ft == 192) hipLaunchKernelGGL(k_photo_stream<192>, grid, dim3(192), 0, stream, P);
+    else hipLaunchKernelGGL(k_photo_stream<256>, grid, dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k_photo_final, dim3(n_views), dim3(kBlock), 0, stream, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return t4d_internal_fail(T4D_ERR_HIP, "t4d_photometric_loss launch: %s", hipGetErrorString(e));
