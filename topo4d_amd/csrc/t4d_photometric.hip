@@ -373,8 +373,8 @@ T4D_EXPORT int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const f
 
 // strips and row segments for an H x W image.  A strip of kFT threads yields kFT - 20 output columns: the launch picks the
 // instantiation (64, 128, 192 or 256 threads) that covers the image width with the fewest thread-columns (512 wide: 3 strips
-// of 171 columns on 192 threads; ties go to the wider strip).  Segments of 128 rows from 16 M values per batch on, 64 from
-// 2 M, 16 below (one view of Topo4D's 512 x 375 images: more, shorter workgroups of a single wave - every segment pays 21
+// of 171 columns on 192 threads; ties go to the wider strip).  Segments of 256 rows from 128 M values per batch on (24 x 2048^2:
+// 2.25 against 2.32 ms with 128), 128 from 16 M, 64 from 2 M, 16 below (one view of Topo4D's 512 x 375 images: more, shorter workgroups of a single wave - every segment pays 21
 // warm-up rows, but a lone view is latency-bound).  T4D_PH_THREADS / T4D_PH_ROWS override (sweeps: tools/sweep_loss_kernels.py).
 static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty, int *tw, int *th, int *threads)
 {
@@ -391,7 +391,7 @@ static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty
     *threads = best;
     *tx = (W + (best - 4 * kR) - 1) / (best - 4 * kR);
     *tw = (W + *tx - 1) / *tx;
-    *th = work >= (1ll << 24) ? 128 : (work >= (1ll << 21) ? 64 : 16);
+    *th = work >= (1ll << 27) ? 256 : (work >= (1ll << 24) ? 128 : (work >= (1ll << 21) ? 64 : 16));
     if (const char *e = getenv("T4D_PH_ROWS")) *th = atoi(e) > 0 ? atoi(e) : *th;      // experiments
     if (*th > H) *th = H;
     *ty = (H + *th - 1) / *th;
