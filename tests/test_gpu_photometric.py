@@ -141,3 +141,37 @@ def test_gradient_does_not_depend_on_the_strip_partition(shape, monkeypatch):
         for x, y in zip(o[2:], out[0][2:]):
             assert np.abs(x - y).max() <= 1e-5 * np.abs(y).max()
     assert np.isfinite(out[0][0]).all() and np.abs(out[0][1]).max() > 0
+
+
+def test_random_shapes_against_the_float64_restatement():
+    """Forty random batches - one to four views, images from 1 x 1 to 90 x 330 (narrower than a window, narrower than a strip's
+    halo, one row, widths that leave a last strip of one column ...) - against the float64 torch restatement of the reference:
+    loss 3e-6 absolute, dL/dim and the camera gradients 5e-5 of their largest entry (plus the L1 term's jump where x' == gt to
+    the last bit)."""
+    rng = np.random.default_rng(7)
+    shapes = [(1, 1, 1), (1, 1, 40), (2, 40, 1), (1, 11, 20), (1, 5, 21), (3, 12, 44), (1, 64, 45), (2, 17, 172), (1, 33, 173)]
+    while len(shapes) < 40:
+        shapes.append((int(rng.integers(1, 5)), int(rng.integers(1, 91)), int(rng.integers(1, 331))))
+    for n, (V, H, W) in enumerate(shapes):
+        g = torch.Generator().manual_seed(100 + n)
+        im = torch.rand(V, 3, H, W, generator=g)
+        gt = (im + torch.randn(V, 3, H, W, generator=g) * 0.1).clamp(0, 1)
+        cm = torch.randn(V, 3, generator=g) * 0.1
+        cc = torch.randn(V, 3, generator=g) * 0.05
+        wv = torch.rand(V, generator=g) + 0.5
+        a = [t.cuda().requires_grad_(True) for t in (im, cm, cc)]
+        l = loss.photometric_loss(a[0], gt.cuda(), a[1], a[2])
+        (l * wv.cuda()).sum().backward()
+        b = [t.double().requires_grad_(True) for t in (im, cm, cc)]
+        lref = torch.stack([loss.photometric_loss_torch(b[0][v], gt[v].double(), b[1][v], b[2][v]) for v in range(V)])
+        (lref * wv.double()).sum().backward()
+        assert torch.allclose(l.double().cpu(), lref, atol=3e-6, rtol=0), (V, H, W)
+        l1_step = 2 * 0.8 * float(wv.max()) / (3 * H * W)
+        for x, y in zip(a, b):
+            gx, gy = x.grad.double().cpu(), y.grad
+            err = (gx - gy).abs()
+            tol = 5e-5 * gy.abs().max() + 1e-12
+            if gx.dim() == 4:
+                assert err.max() <= tol + l1_step * 1.01 and (err > tol).float().mean() <= 1e-3, (V, H, W, float(err.max()))
+            else:
+                assert err.max() <= tol + l1_step * H * W, (V, H, W)
