@@ -17,11 +17,15 @@ def ref():
     l = sum(loss.photometric_loss_torch(im[v], gt[v], cm[v], cc[v]) for v in range(V)); l.backward()
 out = {}
 for name, fn, reps in (("fused_hip", fused, 50), ("torch_per_view", ref, 5)):
-    fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    torch.cuda.synchronize()
-    out[name + "_ms_per_24_views"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+    for _ in range(3): fn()                          # (allocator, module load, clocks: the first loop of a process is not the steady state)
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / reps * 1e3)
+    out[name + "_ms_per_24_views"] = round(best, 3)
 # the library call alone (no autograd glue): HIP events around back-to-back calls -> kernel time of the loss + gradient
 import ctypes as C
 from topo4d_amd import _lib
@@ -45,6 +49,6 @@ out["kernels_us_24x2048x2048"] = raw(24, 2048, 2048, 5)
 out["alg_bytes_24x512x512"] = 24 * 3 * 512 * 512 * 12          # read im + gt, write dL/dim
 out["alg_GBs_24x512x512"] = round(out["alg_bytes_24x512x512"] / (out["kernels_us_24x512x512"] * 1e-6) / 1e9, 1)
 out["alg_GBs_24x2048x2048"] = round(24 * 3 * 2048 * 2048 * 12 / (out["kernels_us_24x2048x2048"] * 1e-6) / 1e9, 1)
-out["bound"] = "vector ALU (two separable 11-tap filters of 5 + 3 maps and the SSIM algebra: ~290 instructions per pixel row and thread)"
+out["bound"] = "vector ALU (two separable 11-tap filters of 4 + 3 maps and the SSIM algebra: ~160 vector instructions per pixel row and thread, 154 multiply-adds among them)"
 out["speedup"] = round(out["torch_per_view_ms_per_24_views"] / out["fused_hip_ms_per_24_views"], 1)
 print(json.dumps(out))
