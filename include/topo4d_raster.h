@@ -205,8 +205,11 @@ typedef struct T4DAdamTensor {
     float lr;
     int32_t step;               /* 1-based count of the gradient steps THIS tensor has taken, this one included (torch keeps
                                    the step per parameter; a tensor skipped for lack of a gradient does not advance) */
-    int32_t reserved;
+    int32_t flags;              /* T4D_ADAM_CLEAR_GRAD: the step leaves zeros in `grad` (a persistent gradient buffer that the next
+                                   iteration fills only in part - the per-camera rows of cam_m / cam_c, train.py:310 - needs no
+                                   separate fill launch); 0 otherwise */
 } T4DAdamTensor;
+#define T4D_ADAM_CLEAR_GRAD 1
 int t4d_adam_pin_step(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
                       void *hip_stream);
 /* The same step with its per-tensor hyper-parameters in DEVICE memory, so that the launch can be recorded in a HIP graph

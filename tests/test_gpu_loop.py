@@ -167,3 +167,59 @@ def test_graphed_views_replay_equals_the_eager_loop():
     for k in pg:
         assert torch.allclose(pg[k], pe[k], rtol=2e-6, atol=1e-7), (k, (pg[k] - pe[k]).abs().max())
     assert torch.equal(pg['means3D'][pins], p0['means3D'].cuda()[pins])
+
+
+def test_explicit_graphed_iteration_is_the_autograd_capture_bit_for_bit():
+    """loop.GraphedViews chains the iteration by hand when it can (explicit_iteration: the same five library calls without the
+    fill / copy / multiply launches autograd puts around them; the camera-affine gradients land in persistent buffers that the
+    Adam step clears; the forward's status goes to pinned host memory without a copy node).  Parameters, optimiser state and
+    losses after a schedule of replays - with a learning-rate change on the way - must equal the autograd capture's bit for bit."""
+    import topo4d_amd
+    from tests import util
+    from scaffold import scene
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    H, W = 64, 80
+    p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)
+    p0['log_scales'] = p0['log_scales'] + torch.randn(240, 3, generator=torch.Generator().manual_seed(9)) * 0.3
+    p0['cam_m'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(2)) * 0.05
+    p0['cam_c'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(3)) * 0.05
+    cams = util.to_device(scene.camera_rig(H, W, n_views=3), "cuda")
+    g = torch.Generator().manual_seed(5)
+    dataset = [{'cam': cams[i], 'im': torch.rand(3, H, W, generator=g).cuda(), 'id': i} for i in range(3)]
+    lrs = {'means3D': 1.6e-4, 'rgb_colors': 0.0025, 'unnorm_rotations': 0.001, 'logit_opacities': 0.05, 'log_scales': 0.001,
+           'cam_m': 1e-3, 'cam_c': 1e-3}
+    schedule = [0, 2, 1, 1, 0, 2, 2, 0, 1, 0, 1, 2]
+    pins = torch.arange(0, 240, 5).cuda()
+
+    def run(explicit):
+        params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=True)
+        opt.set_pin('means3D', pins, params['means3D'][pins].detach().clone())
+        gv = loop.GraphedViews(params, dataset, opt, explicit=explicit)
+        assert gv.explicit == explicit and not opt.clear_grad
+        losses = []
+        for it, c in enumerate(schedule):
+            if it == 5:
+                for grp in opt.param_groups:
+                    if grp['name'] == 'rgb_colors':
+                        grp['lr'] = 0.00025
+            losses.append(gv.step(c).clone())
+        gv.check()
+        assert opt.steps()[0] == len(schedule)
+        state = {k: (opt.state[v]['exp_avg'].clone(), opt.state[v]['exp_avg_sq'].clone()) for k, v in params.items()}
+        return {k: v.detach().clone() for k, v in params.items()}, torch.stack(losses), state, gv
+
+    pe, le, se, gve = run(True)
+    pa, la, sa, _ = run(False)
+    assert torch.equal(le, la)
+    for k in pe:
+        assert torch.equal(pe[k], pa[k]), (k, (pe[k] - pa[k]).abs().max())
+        assert torch.equal(se[k][0], sa[k][0]) and torch.equal(se[k][1], sa[k][1]), k
+    assert (pe['cam_m'] != p0['cam_m'].cuda()).any() and (pe['logit_opacities'] != p0['logit_opacities'].cuda()).any()
+    assert gve._status_host is not None                 # one small view per launch: the status needed no copy node
+    assert len(gve.means2D_grads) == 3 and gve.means2D_grads[0].shape == (240, 3)
+    with pytest.raises(ValueError):
+        params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=True)
+        loop.GraphedViews(params, dataset, opt, extra_loss=lambda p, rv: p['means3D'].sum() * 0, explicit=True)

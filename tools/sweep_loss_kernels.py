@@ -45,8 +45,6 @@ else:
 ref = {}
 for env in variants:
     for (V, H, W, reps) in shapes:
-        if "T4D_PH_ROWS" in env and V == 1:
-            continue
         t, l, d, dm, dc = run(V, H, W, reps, env)
         key = (V, H, W)
         if not env:

@@ -73,7 +73,10 @@ T4D_ADAM_MAX_TENSORS = 12
 class T4DAdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("pin_mask", C.c_void_p), ("pin_values", C.c_void_p), ("rows", C.c_int64), ("width", C.c_int32),
-                ("lr", C.c_float), ("step", C.c_int32), ("reserved", C.c_int32)]
+                ("lr", C.c_float), ("step", C.c_int32), ("flags", C.c_int32)]
+
+
+T4D_ADAM_CLEAR_GRAD = 1
 
 
 class ExtensionMissing(RuntimeError):

@@ -10,50 +10,64 @@ from __future__ import annotations
 import torch
 
 
+def activate_forward(unnorm_rotations, logit_opacities, log_scales):
+    """rotations, opacities, scales = normalize(unnorm_rotations), sigmoid(logit_opacities), exp(log_scales) in ONE launch
+    (t4d_activate_forward); no autograd - contiguous fp32 HIP tensors in, new tensors out."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    dev = unnorm_rotations.device
+    if dev.type != "cuda":
+        raise RuntimeError("params2rendervar_fused runs on the GPU only (no CPU fallback)")
+    ur, lo, ls = unnorm_rotations, logit_opacities, log_scales
+    rot, op, sc = torch.empty_like(ur), torch.empty_like(lo), torch.empty_like(ls)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.t4d_activate_forward(ur.shape[0], p(ur), p(lo), p(ls), p(rot), p(op), p(sc), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"t4d_activate_forward failed (code {rc}): {_lib.last_error()}")
+    return rot, op, sc
+
+
+def activate_backward(unnorm_rotations, opacities, scales, g_rot, g_op, g_sc, need=(True, True, True)):
+    """The vector-Jacobian products of activate_forward in one launch (t4d_activate_backward): `opacities` / `scales` are the
+    forward OUTPUTS, a None cotangent counts as zeros; returns (d_unnorm_rotations, d_logit_opacities, d_log_scales)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    ur, op, sc = unnorm_rotations, opacities, scales
+    dev = ur.device
+    d_ur = torch.empty_like(ur) if need[0] else None
+    d_lo = torch.empty_like(op) if need[1] else None
+    d_ls = torch.empty_like(sc) if need[2] else None
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rc = lib.t4d_activate_backward(ur.shape[0], p(ur), p(op), p(sc), p(g_rot), p(g_op), p(g_sc), p(d_ur), p(d_lo), p(d_ls),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"t4d_activate_backward failed (code {rc}): {_lib.last_error()}")
+    return d_ur, d_lo, d_ls
+
+
 class _Activate(torch.autograd.Function):
     """rotations, opacities, scales = normalize(unnorm_rotations), sigmoid(logit_opacities), exp(log_scales) in ONE launch
     (t4d_activate_forward) and their vector-Jacobian products in one more (t4d_activate_backward)."""
 
     @staticmethod
     def forward(ctx, unnorm_rotations, logit_opacities, log_scales):
-        import ctypes as C
-        from . import _lib
-        lib = _lib.load()
-        dev = unnorm_rotations.device
-        if dev.type != "cuda":
+        if unnorm_rotations.device.type != "cuda":
             raise RuntimeError("params2rendervar_fused runs on the GPU only (no CPU fallback)")
         ur = unnorm_rotations.detach().contiguous().float()
         lo = logit_opacities.detach().contiguous().float()
         ls = log_scales.detach().contiguous().float()
-        P = ur.shape[0]
-        rot, op, sc = torch.empty_like(ur), torch.empty_like(lo), torch.empty_like(ls)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        rc = lib.t4d_activate_forward(P, p(ur), p(lo), p(ls), p(rot), p(op), p(sc), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"t4d_activate_forward failed (code {rc}): {_lib.last_error()}")
+        rot, op, sc = activate_forward(ur, lo, ls)
         ctx.save_for_backward(ur, op, sc)
         ctx.set_materialize_grads(False)
         return rot, op, sc
 
     @staticmethod
     def backward(ctx, g_rot, g_op, g_sc):
-        import ctypes as C
-        from . import _lib
-        lib = _lib.load()
         ur, op, sc = ctx.saved_tensors
-        dev = ur.device
-        need = ctx.needs_input_grad
         c = lambda g: None if g is None else g.contiguous().float()
-        g_rot, g_op, g_sc = c(g_rot), c(g_op), c(g_sc)
-        d_ur = torch.empty_like(ur) if need[0] else None
-        d_lo = torch.empty_like(op) if need[1] else None
-        d_ls = torch.empty_like(sc) if need[2] else None
-        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        rc = lib.t4d_activate_backward(ur.shape[0], p(ur), p(op), p(sc), p(g_rot), p(g_op), p(g_sc), p(d_ur), p(d_lo), p(d_ls),
-                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"t4d_activate_backward failed (code {rc}): {_lib.last_error()}")
-        return d_ur, d_lo, d_ls
+        return activate_backward(ur, op, sc, c(g_rot), c(g_op), c(g_sc), ctx.needs_input_grad)
 
 
 def params2rendervar_fused(params):

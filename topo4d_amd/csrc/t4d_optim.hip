@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
         T.exp_avg_sq[i] = v;
         const float denom = sqrtf(v) * inv_bc2_sqrt + A.eps;
         p = p - step_size * (m / denom);
+        if (T.flags & T4D_ADAM_CLEAR_GRAD) const_cast<float *>(T.grad)[i] = 0.f;
     }
     if (T.pin_mask && T.pin_mask[i / T.width]) p = T.pin_values[i];
     T.param[i] = p;

@@ -20,7 +20,7 @@ from typing import Callable, List, Optional
 import torch
 
 from . import loss as t4d_loss
-from .boundary import params2rendervar_fused
+from .boundary import activate_backward, activate_forward, params2rendervar_fused
 from .rasterizer import GaussianRasterizer
 
 
@@ -55,6 +55,53 @@ def photometric_iteration(params, curr_data, fused_loss: bool = True, extra_loss
     if extra_loss is not None:
         l = l + extra_loss(params, rendervar)
     return l, radius, rendervar
+
+
+_RENDER_KEYS = ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales')
+
+
+def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
+    """photometric_iteration + loss.backward() WITHOUT autograd: the same launches - t4d_activate_forward, t4d_rasterize_forward,
+    t4d_photometric_loss, t4d_rasterize_backward, t4d_activate_backward - chained by hand, and none of the launches autograd
+    puts around them (the zeros + 0 of means2D, ones_like for the root, a fill and a copy for every `[cid]` / `[0]` it
+    differentiates through, the multiplication of dL/dim by a cotangent of one: nine launches of 4-5 us per iteration, a third
+    of a 148 us graphed iteration).  For the precomputed-RGB, scale + rotation parametrisation of train.py:303-315 with the
+    fused loss and no extra loss term.
+    `cam_grads`: {'cam_m': [n_cams, 3], 'cam_c': ...} persistent ZERO buffers; the loss kernel writes row `id` of each.
+    `status_sink`: data pointer of 16 bytes of pinned host memory for the forward's status block (ViewBatch.status_sink).
+    Returns (loss: device scalar, radius, grads: {parameter name: gradient tensor}, ViewBatch, dL/dmeans2D)."""
+    from . import rasterizer as R
+    cam = curr_data['cam']
+    dev = params['means3D'].device
+    d = lambda k: params[k].detach()
+    ur = d('unnorm_rotations')
+    rot, op, sc = activate_forward(ur, d('logit_opacities'), d('log_scales'))
+    batch = R.ViewBatch(R.pack_views([cam], dev), int(cam.image_height), int(cam.image_width), float(cam.scale_modifier),
+                        int(cam.sh_degree), debug=bool(cam.debug), prefiltered=bool(cam.prefiltered), cam_key=id(cam))
+    batch.flat_grads = True                               # the drop-in's shapes: no view axis
+    batch.status_sink = status_sink                       # (lazy mode: pinned host words for the forward's status block)
+    im, radius, _, _ = batch.forward(d('means3D'), op, sc, rot, colors_precomp=d('rgb_colors'))
+    cid = curr_data['id']
+    cm = cc = dcm = dcc = None
+    if 'cam_m' in params:
+        cm, cc = d('cam_m')[cid:cid + 1], d('cam_c')[cid:cid + 1]
+        if cam_grads is not None:
+            dcm, dcc = cam_grads['cam_m'][cid:cid + 1], cam_grads['cam_c'][cid:cid + 1]
+    gt = curr_data['im']
+    l, d_im, dcm, dcc = t4d_loss.photometric_loss_raw(im[None], gt[None] if gt.is_contiguous() else gt.contiguous()[None], cm, cc, dcm, dcc)
+    g = batch.backward(d_im)
+    d_ur, d_lo, d_ls = activate_backward(ur, op, sc, g['rotations'], g['opacities'], g['scales'])
+    grads = {'means3D': g['means3D'], 'rgb_colors': g['colors_precomp'], 'unnorm_rotations': d_ur, 'logit_opacities': d_lo,
+             'log_scales': d_ls}
+    if cm is not None:
+        if cam_grads is not None:
+            grads['cam_m'], grads['cam_c'] = cam_grads['cam_m'], cam_grads['cam_c']
+        else:                                             # no persistent buffers: a full-size gradient with one row set
+            for k, row in (('cam_m', dcm), ('cam_c', dcc)):
+                full = torch.zeros_like(params[k])
+                full[cid:cid + 1] = row
+                grads[k] = full
+    return l[0], radius, grads, batch, g['means2D']
 
 
 def optimise_views(params, dataset: List[dict], optimizer, n_iters: int, seed: int = 0, fused_loss: bool = True,
@@ -95,7 +142,8 @@ class GraphedViews:
     gv.check() reads the overflow flags back.
     """
 
-    def __init__(self, params, dataset: List[dict], optimizer, fused_loss: bool = True, extra_loss: Optional[Callable] = None):
+    def __init__(self, params, dataset: List[dict], optimizer, fused_loss: bool = True, extra_loss: Optional[Callable] = None,
+                 explicit: Optional[bool] = None):
         from . import rasterizer as R
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedViews needs FusedAdamPins(..., capturable=True)")
@@ -103,6 +151,21 @@ class GraphedViews:
         dev = params['means3D'].device
         if dev.type != "cuda":
             raise RuntimeError("GraphedViews runs on the GPU only")
+        # explicit: the iteration chained by hand (explicit_iteration) instead of recorded through autograd - the same
+        # arithmetic without autograd's fill / copy / multiply launches (parameters after any number of steps are bit-identical,
+        # tests/test_gpu_loop.py).  Needs the fused loss, no extra loss term and the scale + rotation / RGB parametrisation.
+        can = fused_loss and extra_loss is None and all(k in params for k in _RENDER_KEYS) and \
+            ('cam_m' in params) == ('cam_c' in params)
+        if explicit and not can:
+            raise ValueError("explicit=True needs the fused loss, no extra_loss, and the parameters " + ", ".join(_RENDER_KEYS))
+        self.explicit = can if explicit is None else bool(explicit)
+        self._cam_grads = None
+        self._clear_before = set(optimizer.clear_grad)
+        if self.explicit and 'cam_m' in params:
+            # persistent gradient buffers of the per-camera affine: an iteration writes ONE row, the step leaves zeros behind
+            self._cam_grads = {k: torch.zeros_like(params[k]) for k in ('cam_m', 'cam_c')}
+            optimizer.clear_grad |= {g["name"] for g in optimizer.param_groups if g["params"][0] is params['cam_m'] or g["params"][0] is params['cam_c']}
+        self.graphs, self._status_host = [], None
         leaves = [g["params"][0] for g in optimizer.param_groups]
         # the warm-up below takes real optimisation steps; everything it touches is restored before the captures
         snap_p = [p.detach().clone() for p in leaves]
@@ -112,11 +175,14 @@ class GraphedViews:
         with torch.cuda.stream(side):
             R.set_sync_mode("checked")
             for data in dataset:                                   # learns the pair-arena capacity of every camera
-                l, _, _ = photometric_iteration(params, data, fused_loss, extra_loss)
-                l.backward()
-                with torch.no_grad():
-                    optimizer.step()
-                    optimizer.zero_grad(set_to_none=True)
+                if self.explicit:
+                    self._explicit_step(data)
+                else:
+                    l, _, _ = photometric_iteration(params, data, fused_loss, extra_loss)
+                    l.backward()
+                    with torch.no_grad():
+                        optimizer.step()
+                optimizer.zero_grad(set_to_none=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         with torch.no_grad():
@@ -128,13 +194,16 @@ class GraphedViews:
                     st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"] = 0
             optimizer._hyper(dev)[0].zero_()
         optimizer.sync_hyper()
-        self.graphs, self.losses, self.radii = [], [], []
+        self.graphs, self.losses, self.radii, self.means2D_grads = [], [], [], []
         # every tensor a captured kernel reads through a raw pointer must outlive the graphs: the packed camera records are
         # otherwise owned only by the rasterizer's (evicting) view cache
         self._keep = []
         # binning status words (overflow flag, pairs needed) of every captured forward, copied out INSIDE its graph: the
         # graphs share one memory pool, so a state buffer is only meaningful until the next graph replays
         self._status = torch.zeros(len(dataset), 4, dtype=torch.int32, device=dev)
+        # explicit iterations of ONE small view: the binning kernel writes its status block into pinned host memory itself
+        # (T4D_FLAG_ASYNC_STATUS): no copy node in the graph.  Each camera's 16 bytes start out as "nothing wrong".
+        self._status_host = torch.zeros(len(dataset), 2, dtype=torch.int64).pin_memory() if self.explicit else None
         self._caps = []
         R.set_sync_mode("lazy")
         try:
@@ -147,6 +216,22 @@ class GraphedViews:
             R._BATCH_LOG = None
             R._restore_sync_mode(prev_mode)
         optimizer.zero_grad(set_to_none=True)
+        optimizer.clear_grad = self._clear_before          # (the flag is recorded in the graphs; eager steps keep their gradients)
+        if self._cam_grads is not None:
+            # the replays read the persistent buffers through the pointers recorded in the graphs; `.grad` stays None between steps
+            for b in self._cam_grads.values():
+                b.zero_()
+
+    def _explicit_step(self, data):
+        """One iteration chained by hand: gradients handed to the optimiser as `.grad`, then the fused step."""
+        sink = None
+        if self._status_host is not None and torch.cuda.is_current_stream_capturing():
+            sink = self._status_host.data_ptr() + 16 * len(self.graphs)
+        l, radius, grads, batch, g2d = explicit_iteration(self.params, data, self._cam_grads, sink)
+        for k, gr in grads.items():
+            self.params[k].grad = gr
+        self.opt.step()
+        return l, radius, batch, (grads, g2d)
 
     def _capture_all(self, R, fused_loss, extra_loss) -> None:
         pool = None
@@ -155,12 +240,21 @@ class GraphedViews:
             R._BATCH_LOG = []
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
-                l, radius, _ = photometric_iteration(self.params, data, fused_loss, extra_loss)
-                batch = R._BATCH_LOG[-1]
+                if self.explicit:
+                    l, radius, batch, keep = self._explicit_step(data)
+                    self._keep.append((batch, keep))
+                    self.means2D_grads.append(keep[1])
+                    if not (batch.prob.flags & R._lib.T4D_FLAG_ASYNC_STATUS):        # (the library took the status sink?)
+                        self._status_host = None
+                    if self._status_host is None:
+                        self._status[len(self.graphs)].copy_(batch.state[:16].view(torch.int32))
+                else:
+                    l, radius, _ = photometric_iteration(self.params, data, fused_loss, extra_loss)
+                    batch = R._BATCH_LOG[-1]
+                    self._status[len(self.graphs)].copy_(batch.state[:16].view(torch.int32))
+                    l.backward()
+                    self.opt.step()
                 self._keep.append(batch.views)
-                self._status[len(self.graphs)].copy_(batch.state[:16].view(torch.int32))
-                l.backward()
-                self.opt.step()
             pool = g.pool()
             self.graphs.append(g)
             self.losses.append(l.detach())
@@ -176,7 +270,12 @@ class GraphedViews:
 
     def check(self) -> None:
         """Synchronising read of every captured forward's binning status: raises if a replay was truncated."""
-        for i, (overflow, need, _, _) in enumerate(self._status.tolist()):
+        if self._status_host is not None:
+            torch.cuda.synchronize(self._status.device)
+            words = [(int(w0) & 0xffffffff, (int(w0) >> 32) & 0xffffffff, 0, 0) for w0, _ in self._status_host.tolist()]
+        else:
+            words = self._status.tolist()
+        for i, (overflow, need, _, _) in enumerate(words):
             if overflow:
                 raise RuntimeError(f"the graphed render of camera {i} needed {need} (Gaussian,tile) pairs per view, its recorded arena "
                                    f"holds {self._caps[i]}; build a new GraphedViews on the current scene")

@@ -53,31 +53,43 @@ def photometric_loss_torch(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tens
 # ------------------------------------------------------------------------------------------------------------
 # fused HIP version (t4d_photometric_loss): forward + gradient in one launch set for a batch of views
 # ------------------------------------------------------------------------------------------------------------
+def photometric_loss_raw(im, gt, cam_m=None, cam_c=None, d_cam_m=None, d_cam_c=None):
+    """t4d_photometric_loss without autograd: contiguous fp32 HIP tensors im, gt [V,3,H,W], cam_m / cam_c [V,3] or None.
+    Returns (loss [V], dL/dim [V,3,H,W], dL/dcam_m, dL/dcam_c); `d_cam_m` / `d_cam_c`: [V,3] tensors that receive the camera
+    gradients (e.g. rows of a persistent gradient buffer), allocated here when None."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    if not im.is_cuda:
+        raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+    V, _, H, W = im.shape
+    dev = im.device
+    loss = torch.empty(V, dtype=torch.float32, device=dev)
+    d_im = torch.empty_like(im)
+    have_cam = cam_m is not None
+    if have_cam and d_cam_m is None:
+        d_cam_m = torch.empty(V, 3, dtype=torch.float32, device=dev)
+        d_cam_c = torch.empty(V, 3, dtype=torch.float32, device=dev)
+    nbytes = lib.t4d_photometric_scratch_bytes(V, H, W)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rc = lib.t4d_photometric_loss(V, H, W, p(im), p(gt), p(cam_m), p(cam_c), None, p(loss), p(d_im),
+                                  p(d_cam_m) if have_cam else None, p(d_cam_c) if have_cam else None,
+                                  p(scratch), nbytes, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"t4d_photometric_loss failed (code {rc}): {_lib.last_error()}")
+    return loss, d_im, (d_cam_m if have_cam else None), (d_cam_c if have_cam else None)
+
+
 class _FusedPhotometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, gt, cam_m, cam_c):
-        import ctypes as C
-        from . import _lib
-        lib = _lib.load()
         if not im.is_cuda:
             raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
-        im_c, gt_c = im.float().contiguous(), gt.float().contiguous()
-        V, _, H, W = im_c.shape
-        dev = im_c.device
-        loss = torch.empty(V, dtype=torch.float32, device=dev)
-        d_im = torch.empty_like(im_c)
         have_cam = cam_m is not None
-        cm = cam_m.float().contiguous() if have_cam else None
-        cc = cam_c.float().contiguous() if have_cam else None
-        d_m = torch.empty(V, 3, dtype=torch.float32, device=dev) if have_cam else None
-        d_c = torch.empty(V, 3, dtype=torch.float32, device=dev) if have_cam else None
-        nbytes = lib.t4d_photometric_scratch_bytes(V, H, W)
-        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        rc = lib.t4d_photometric_loss(V, H, W, p(im_c), p(gt_c), p(cm), p(cc), None, p(loss), p(d_im), p(d_m), p(d_c),
-                                      p(scratch), nbytes, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"t4d_photometric_loss failed (code {rc}): {_lib.last_error()}")
+        loss, d_im, d_m, d_c = photometric_loss_raw(im.float().contiguous(), gt.float().contiguous(),
+                                                    cam_m.float().contiguous() if have_cam else None,
+                                                    cam_c.float().contiguous() if have_cam else None)
         ctx.save_for_backward(d_im, d_m, d_c)
         return loss
 

@@ -36,6 +36,9 @@ class FusedAdamPins:
         # capturable: step counts and learning rates live in device memory (t4d_adam_pin_step_graph), so that step() can be
         # recorded in a HIP graph and replayed (loop.GraphedViews); call sync_hyper() after changing a group's 'lr'
         self.capturable = capturable
+        # names of the tensors whose gradient buffer step() leaves ZEROED (T4D_ADAM_CLEAR_GRAD): persistent buffers that an
+        # iteration fills only in part (loop.GraphedViews: the per-camera rows of cam_m / cam_c)
+        self.clear_grad: set = set()
         self._step_dev: Optional[torch.Tensor] = None
         self._lr_dev: Optional[torch.Tensor] = None
         self._lr_host: Optional[List[float]] = None
@@ -146,7 +149,8 @@ class FusedAdamPins:
             ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
             arr[k] = _lib.T4DAdamTensor(ptr(p), ptr(grad), ptr(st.get("exp_avg")) if grad is not None else None,
                                         ptr(st.get("exp_avg_sq")) if grad is not None else None, ptr(mask), ptr(vals), rows,
-                                        width, float(g["lr"]), int(st.get("step", 0)) if grad is not None else 0, 0)
+                                        width, float(g["lr"]), int(st.get("step", 0)) if grad is not None else 0,
+                                        _lib.T4D_ADAM_CLEAR_GRAD if (grad is not None and g["name"] in self.clear_grad) else 0)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if self.capturable:
             if not torch.cuda.is_current_stream_capturing():

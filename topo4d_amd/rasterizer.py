@@ -372,6 +372,10 @@ class ViewBatch:
         self.plan = None
         self.pending = None
         self.flat_grads = False                         # True (autograd path, V = 1): gradients come back without the view axis
+        # lazy mode only: 16 bytes of PINNED host memory (data pointer) that receive this forward's raw status block
+        # { overflow | pairs needed << 32, total pairs } - a one-view launch's binning kernel writes them itself, so a captured
+        # iteration (loop.GraphedViews) needs no copy node to keep the status of its forward
+        self.status_sink = None
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def _flags(self, P: int, checked: bool) -> int:
@@ -477,6 +481,9 @@ class ViewBatch:
                 flags |= _lib.T4D_FLAG_ASYNC_STATUS
                 pending = track.claim(cap)
                 status_arg = track.args[pending.slot]
+            elif self.status_sink is not None and not checked:
+                flags |= _lib.T4D_FLAG_ASYNC_STATUS
+                status_arg = C.cast(C.c_void_p(int(self.status_sink)), C.POINTER(T4DStatus))
             prob = T4DProblem(T4D_ABI_VERSION, V, P, H, W, self.sh_degree, M, self.scale_modifier, cap, flags, 0)
             nbytes = plan.state_bytes.get(cap)
             if nbytes is None:
