@@ -115,9 +115,10 @@ def test_masked_l1_matches_reference_golden_g8_and_torch():
 @pytest.mark.parametrize("shape", [(1, 512, 375), (2, 97, 210), (24, 128, 128)])
 def test_gradient_does_not_depend_on_the_strip_partition(shape, monkeypatch):
     """k_photo_stream cuts a plane into strips of kFT - 20 columns and segments of rows (T4D_PH_THREADS / T4D_PH_ROWS force
-    them).  A pixel's arithmetic and its order do not depend on which strip or segment it falls in: dL/dim must be
-    bit-identical under every partition; the loss and the camera gradients are sums over another fixed partition and agree to
-    rounding."""
+    them); small launches take k_photo_tile (tiles of 64 x 44 or 32 x 44 pixels, the four filter passes as phases over LDS;
+    T4D_PH_TILE forces either kernel and the small tile shape).  A pixel's arithmetic and its order do not depend on the kernel, strip, segment or tile it falls in: dL/dim
+    must be bit-identical under every partition; the loss and the camera gradients are sums over another fixed partition and
+    agree to rounding."""
     V, H, W = shape
     g = torch.Generator().manual_seed(5)
     im = torch.rand(V, 3, H, W, generator=g).cuda()
@@ -125,16 +126,21 @@ def test_gradient_does_not_depend_on_the_strip_partition(shape, monkeypatch):
     cm = (torch.randn(V, 3, generator=g) * 0.1).cuda()
     cc = (torch.randn(V, 3, generator=g) * 0.05).cuda()
     out = []
-    for threads, rows in (("", ""), ("64", "16"), ("128", "37"), ("192", "64"), ("256", "512")):
-        if threads:
-            monkeypatch.setenv("T4D_PH_THREADS", threads)
-            monkeypatch.setenv("T4D_PH_ROWS", rows)
+    keys = ("T4D_PH_TILE", "T4D_PH_THREADS", "T4D_PH_ROWS")
+    for env in ({}, {"T4D_PH_TILE": "1"}, {"T4D_PH_TILE": "32"}, {"T4D_PH_TILE": "0"}, {"T4D_PH_TILE": "0", "T4D_PH_THREADS": "64", "T4D_PH_ROWS": "16"},
+                {"T4D_PH_TILE": "0", "T4D_PH_THREADS": "128", "T4D_PH_ROWS": "37"},
+                {"T4D_PH_TILE": "0", "T4D_PH_THREADS": "192", "T4D_PH_ROWS": "64"},
+                {"T4D_PH_TILE": "0", "T4D_PH_THREADS": "256", "T4D_PH_ROWS": "512"}):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
         a = [t.clone().requires_grad_(True) for t in (im, cm, cc)]
         l = loss.photometric_loss(a[0], gt, a[1], a[2])
         l.sum().backward()
         out.append([l.detach().cpu().numpy()] + [t.grad.cpu().numpy() for t in a])
-    monkeypatch.delenv("T4D_PH_THREADS", raising=False)
-    monkeypatch.delenv("T4D_PH_ROWS", raising=False)
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
     for o in out[1:]:
         assert np.array_equal(o[1], out[0][1])
         assert np.abs(o[0] - out[0][0]).max() < 1e-6

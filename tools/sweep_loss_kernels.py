@@ -12,7 +12,7 @@ p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 
 
 def run(V, H, W, reps, env):
-    for k in ("T4D_PH_THREADS", "T4D_PH_ROWS"):
+    for k in ("T4D_PH_THREADS", "T4D_PH_ROWS", "T4D_PH_TILE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     g = torch.Generator().manual_seed(V * H + W)

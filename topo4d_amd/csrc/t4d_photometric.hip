@@ -57,6 +57,36 @@ template <int N> struct IC { static constexpr int value = N; };
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));      // packed-math pair: one v_pk_fma_f32 does two of the filter's multiply-adds
 
+// The per-pixel arithmetic both loss kernels share (one source, one rounding): SSIM of the four filtered maps and the three
+// adjoint values, and dL/dx' of an output pixel.
+//   S = A1 A2 / (B1 B2),  s11 + s22 = E[x^2 + y^2] - mu1^2 - mu2^2,  s12 = E[xy] - mu1 mu2;  gsc = dL/dS inside the image, else 0
+__device__ __forceinline__ void ssim_adjoint(const float mu1, const float mu2, const float es, const float ep, const float gsc,
+                                             float &S, float &d1, float &d2, float &d3)
+{
+    const float mu12 = mu1 * mu2;
+    const float B1 = fmaf(mu1, mu1, fmaf(mu2, mu2, kC1));
+    const float B2 = (es - B1) + (kC1 + kC2);
+    const float A1 = fmaf(2.f, mu12, kC1), A2 = fmaf(2.f, ep - mu12, kC2);
+    const float den = B1 * B2;
+    float inv = __builtin_amdgcn_rcpf(den);              // the one reciprocal of the pixel: 1/B1 = B2 inv, 1/B2 = B1 inv
+    inv = fmaf(fmaf(-den, inv, 1.f), inv, inv);
+    S = A1 * A2 * inv;
+    const float gi = gsc * inv;
+    const float gi2 = gi + gi;
+    d1 = gi2 * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
+    d2 = -gi * S * B1;
+    d3 = gi2 * A1;
+}
+// x' = em * im + cc, y = gt, (r0, r1, r2) = G*D1, G*D2, G*D3 at the pixel: returns dL/dx', leaves |x' - y| in `ad`
+__device__ __forceinline__ float pixel_gradient(const float x, const float y, const float r0, const float r1, const float r2,
+                                                const float l1w, float &ad)
+{
+    const float d = x - y;
+    ad = fabsf(d);
+    const float gl1 = d == 0.f ? 0.f : copysignf(l1w, d);                        // 0.8 / N * sign(x' - y)
+    return fmaf(x + x, r1, r0) + fmaf(y, r2, gl1);
+}
+
 // The strip kernel.  A workgroup of kFT threads owns a vertical STRIP of one channel of one view - kFT input columns, hence
 // kFT - 10 first-stage columns and kFT - 20 output columns - and a segment of rows, and streams down it one image row per
 // iteration; every thread owns ONE column of each stage:
@@ -175,21 +205,9 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 m12 = __builtin_elementwise_fma(wk, h01[sl], m12);
                 esp = __builtin_elementwise_fma(wk, h23[sl], esp);
             }
-            // S = A1 A2 / (B1 B2),  s11 + s22 = E[x^2 + y^2] - mu1^2 - mu2^2,  s12 = E[xy] - mu1 mu2
-            const float mu1 = m12.x, mu2 = m12.y, es = esp.x, ep = esp.y;
-            const float mu12 = mu1 * mu2;
-            const float B1 = fmaf(mu1, mu1, fmaf(mu2, mu2, kC1));
-            const float B2 = (es - B1) + (kC1 + kC2);
-            const float A1 = fmaf(2.f, mu12, kC1), A2 = fmaf(2.f, ep - mu12, kC2);
-            const float den = B1 * B2;
-            float inv = __builtin_amdgcn_rcpf(den);              // the one reciprocal of the pixel: 1/B1 = B2 inv, 1/B2 = B1 inv
-            inv = fmaf(fmaf(-den, inv, 1.f), inv, inv);
-            const float S = A1 * A2 * inv;
             const int srow = i - kR;
-            const float gi = ((unsigned)srow < (unsigned)P.H && col1) ? g * inv : 0.f;
-            const float gi2 = gi + gi;
-            const float d1 = gi2 * (mu2 * (A2 - A1) - S * mu1 * (B2 - B1));
-            const float d2 = -gi * S * B1, d3 = gi2 * A1;
+            float S, d1, d2, d3;
+            ssim_adjoint(m12.x, m12.y, esp.x, esp.y, ((unsigned)srow < (unsigned)P.H && col1) ? g : 0.f, S, d1, d2, d3);
             s_d[buf][tid] = (v4f){ d1, d2, d3, 0.f };
             if (srow >= y0 && srow < y1) sum_s += S;     // wave-uniform
         }
@@ -221,12 +239,10 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             if (o_ok) {                                  // wave-uniform: an output row of this segment
                 const float xi = em * o_im;
-                const float x = fmaf(em, o_im, cc), y = o_gt;
-                const float d = x - y;
-                const float gl1 = d == 0.f ? 0.f : copysignf(l1w, d);                        // 0.8 / N * sign(x' - y)
-                const float gg = fmaf(x + x, r01.y, r01.x) + fmaf(y, r2, gl1);               // dL/dx'
+                float ad;
+                const float gg = pixel_gradient(fmaf(em, o_im, cc), o_gt, r01.x, r01.y, r2, l1w, ad);      // dL/dx'
                 if (col2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, em * gg), r_out, off_out, oro, 0);
-                sum_l1 += fabsf(d);
+                sum_l1 += ad;
                 sum_gm = fmaf(gg, xi, sum_gm);           // d x'/d cam_m = exp(cam_m) * im
                 sum_gc += gg;
             }
@@ -242,6 +258,157 @@ __global__ __launch_bounds__(kFT) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     const float tl1 = block_sum(col2 ? sum_l1 : 0.f, s_red), tss = block_sum(own1 ? sum_s : 0.f, s_red);
     const float tgm = block_sum(col2 ? sum_gm : 0.f, s_red), tgc = block_sum(col2 ? sum_gc : 0.f, s_red);
+    if (tid == 0) {
+        const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
+        P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
+        P.part_cam[2 * t] = tgm; P.part_cam[2 * t + 1] = tgc;
+    }
+}
+
+// The TILE kernel for small launches (one to three views of Topo4D's 512 x 375 images: train.py:661-673 computes the loss of ONE
+// view per iteration).  A strip workgroup walks 20 warm-up rows plus its segment one row after the other - 36 dependent rows of
+// ~0.85 us for a lone wave: 31 us for a view whose arithmetic is worth 6.  Here a workgroup of NT threads owns a tile of
+// TH x 44 output pixels and runs the four filter passes as four PHASES over the whole tile, every thread taking its share of a
+// phase's pixels, with the intermediate maps in LDS instead of register windows:
+//   load (TH+20) x 64 inputs -> P1 horizontal 11 taps of (x, y, s, p) -> P2 vertical taps, SSIM, adjoint values (TH+10) x 54
+//   -> P3 horizontal taps of (D1, D2, D3) -> P4 vertical taps, dL/dx', sums.
+// Four barriers instead of TH + 21, a dependent chain of ~2,000 instructions per thread instead of ~5,800.  The arithmetic and
+// its order per pixel are the strip kernel's (ssim_adjoint, pixel_gradient, taps in ascending order): dL/dim is bit-identical
+// whichever kernel a launch takes (tests/test_gpu_photometric.py).  LDS: inputs as (x', y) pairs - s and p are formed per tap
+// here - overlaid by the adjoint values, the first stage's maps overlaid by the second stage's.  Two shapes: 64 x 44 pixels on
+// 1,024 threads (118 KB of LDS: one workgroup per CU, sixteen waves; one 512 x 375 view = 216 tiles) when the launch has at most
+// one tile per CU, else 32 x 44 on 512 threads (71 KB: two per CU) up to two tiles per CU; bigger launches take the strips.
+template <int TH, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_photo_tile(const PhP P)
+{
+    constexpr int TW = 44, IW = TW + 4 * kR, MW = TW + 2 * kR, IH = TH + 4 * kR, DH = TH + 2 * kR;
+    constexpr int kBytesA = (IH * IW * 8 > DH * MW * 12 ? IH * IW * 8 : DH * MW * 12);
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[kBytesA];     // inputs (x', y); then D1 D2 | D3
+    __shared__ v4f s_h[IH * MW];                                            // first-stage maps; then G_h*(D1, D2) | G_h*D3
+    __shared__ float s_red[NT / 64];
+    v2f *s_in = reinterpret_cast<v2f *>(s_a);
+    v2f *s_d01 = reinterpret_cast<v2f *>(s_a);
+    float *s_d2 = reinterpret_cast<float *>(s_a + DH * MW * 8);
+    v2f *s_q01 = reinterpret_cast<v2f *>(s_h);
+    float *s_q2 = reinterpret_cast<float *>(s_h) + 2 * DH * TW;
+    const int tid = threadIdx.x;
+    const int vc = blockIdx.z, v = vc / 3;
+    const int x0 = blockIdx.x * TW, x1 = min(x0 + TW, P.W), y0 = blockIdx.y * TH, y1 = min(y0 + TH, P.H);
+    const size_t HW = (size_t)P.H * P.W;
+    const float *im = P.im + (size_t)vc * HW, *gt = P.gt + (size_t)vc * HW;
+    float *dout = P.dL_dim + (size_t)vc * HW;
+    const float em = P.cam_m ? expf(P.cam_m[vc]) : 1.f, cc = P.cam_c ? P.cam_c[vc] : 0.f;
+    const float N = 3.f * (float)HW, wv = P.weight ? P.weight[v] : 1.f;
+    const float g = -0.2f * wv / N, l1w = 0.8f * wv / N;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = P.win[k];
+    // ---- load: (x', y) of the tile and its 10-pixel frame, zero outside the image (external.py:86 padding=5).  All of a thread's
+    // loads are issued before the first is used (clamped addresses, validity as a select): one round trip, not thirteen
+    constexpr int kIn = (IH * IW + NT - 1) / NT;
+    {
+        float a[kIn], b[kIn];
+#pragma unroll
+        for (int j = 0; j < kIn; j++) {
+            const int i = tid + NT * j, r = i / IW, c = i - r * IW;
+            const size_t o = (size_t)min(max(y0 - 2 * kR + r, 0), P.H - 1) * P.W + min(max(x0 - 2 * kR + c, 0), P.W - 1);
+            a[j] = im[o]; b[j] = gt[o];
+        }
+#pragma unroll
+        for (int j = 0; j < kIn; j++) {
+            const int i = tid + NT * j, r = i / IW, c = i - r * IW, gy = y0 - 2 * kR + r, gx = x0 - 2 * kR + c;
+            const bool ok = (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W;
+            if (i < IH * IW) s_in[i] = (v2f){ ok ? fmaf(em, a[j], cc) : 0.f, ok ? b[j] : 0.f };
+        }
+    }
+    // the output pixels of this thread (phase 4), requested now
+    constexpr int kOut = (TH * TW + NT - 1) / NT;
+    float o_im[kOut], o_gt[kOut];
+#pragma unroll
+    for (int j = 0; j < kOut; j++) {
+        const int i = tid + NT * j, r = i / TW, c = i - r * TW;
+        const int gy = min(y0 + r, P.H - 1), gx = min(x0 + c, P.W - 1);
+        o_im[j] = im[(size_t)gy * P.W + gx]; o_gt[j] = gt[(size_t)gy * P.W + gx];
+    }
+    __syncthreads();
+    // ---- P1: horizontal taps of (x, y, s = x^2 + y^2, p = x y) at IH x MW positions
+    for (int i = tid; i < IH * MW; i += NT) {
+        const int r = i / MW, c = i - r * MW;
+        const v2f *src = s_in + r * IW + c;
+        v2f a01 = { 0.f, 0.f }, a23 = { 0.f, 0.f };
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const v2f q = src[k];
+            const v2f wk = { w[k], w[k] };
+            a01 = __builtin_elementwise_fma(wk, q, a01);
+            a23 = __builtin_elementwise_fma(wk, (v2f){ fmaf(q.x, q.x, q.y * q.y), q.x * q.y }, a23);
+        }
+        s_h[i] = (v4f){ a01.x, a01.y, a23.x, a23.y };
+    }
+    __syncthreads();
+    // ---- P2: vertical taps -> filtered maps at DH x MW positions -> SSIM, adjoint values (over the input pairs: all read)
+    float sum_s = 0.f;
+    for (int i = tid; i < DH * MW; i += NT) {
+        const int r = i / MW, c = i - r * MW;
+        v2f m12 = { 0.f, 0.f }, esp = { 0.f, 0.f };
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const v4f q = s_h[i + k * MW];
+            const v2f wk = { w[k], w[k] };
+            m12 = __builtin_elementwise_fma(wk, (v2f){ q.x, q.y }, m12);
+            esp = __builtin_elementwise_fma(wk, (v2f){ q.z, q.w }, esp);
+        }
+        const int gy = y0 - kR + r, gx = x0 - kR + c;
+        const bool inside = (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W;
+        float S, d1, d2, d3;
+        ssim_adjoint(m12.x, m12.y, esp.x, esp.y, inside ? g : 0.f, S, d1, d2, d3);
+        s_d01[i] = (v2f){ d1, d2 }; s_d2[i] = d3;
+        sum_s += (gy >= y0 && gy < y1 && gx >= x0 && gx < x1) ? S : 0.f;
+    }
+    __syncthreads();
+    // ---- P3: horizontal taps of (D1, D2, D3) at DH x TW positions (over the first-stage maps: all read)
+    for (int i = tid; i < DH * TW; i += NT) {
+        const int r = i / TW, c = i - r * TW;
+        const int src = r * MW + c;
+        v2f q01 = { 0.f, 0.f };
+        float q2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const v2f wk = { w[k], w[k] };
+            q01 = __builtin_elementwise_fma(wk, s_d01[src + k], q01);
+            q2 = fmaf(w[k], s_d2[src + k], q2);
+        }
+        s_q01[i] = q01; s_q2[i] = q2;
+    }
+    __syncthreads();
+    // ---- P4: vertical taps -> dL/dx', affine backward, sums
+    float sum_l1 = 0.f, sum_gm = 0.f, sum_gc = 0.f;
+#pragma unroll
+    for (int j = 0; j < kOut; j++) {
+        const int i = tid + NT * j, r = i / TW, c = i - r * TW;
+        if (i < TH * TW) {
+            v2f r01 = { 0.f, 0.f };
+            float r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const v2f wk = { w[k], w[k] };
+                r01 = __builtin_elementwise_fma(wk, s_q01[i + k * TW], r01);
+                r2 = fmaf(w[k], s_q2[i + k * TW], r2);
+            }
+            const int gy = y0 + r, gx = x0 + c;
+            if (gy < y1 && gx < x1) {
+                const float xi = em * o_im[j];
+                float ad;
+                const float gg = pixel_gradient(fmaf(em, o_im[j], cc), o_gt[j], r01.x, r01.y, r2, l1w, ad);
+                dout[(size_t)gy * P.W + gx] = em * gg;
+                sum_l1 += ad;
+                sum_gm = fmaf(gg, xi, sum_gm);
+                sum_gc += gg;
+            }
+        }
+    }
+    const float tl1 = block_sum(sum_l1, s_red), tss = block_sum(sum_s, s_red);
+    const float tgm = block_sum(sum_gm, s_red), tgc = block_sum(sum_gc, s_red);
     if (tid == 0) {
         const size_t t = ((size_t)vc * P.ty + blockIdx.y) * P.tx + blockIdx.x;
         P.part_loss[2 * t] = tl1; P.part_loss[2 * t + 1] = tss;
@@ -376,9 +543,32 @@ T4D_EXPORT int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const f
 // of 171 columns on 192 threads; ties go to the wider strip).  Segments of 256 rows from 128 M values per batch on (24 x 2048^2:
 // 2.25 against 2.32 ms with 128), 128 from 16 M, 64 from 2 M, 16 below (one view of Topo4D's 512 x 375 images: more, shorter workgroups of a single wave - every segment pays 21
 // warm-up rows, but a lone view is latency-bound).  T4D_PH_THREADS / T4D_PH_ROWS override (sweeps: tools/sweep_loss_kernels.py).
+// (threads = 0: a launch whose tiles are all resident at once takes the TILE kernel - th = 64 when there is at most one tile of
+// 64 x 44 pixels per CU (one view of Topo4D's 512 x 375 images: 216), else th = 32 up to two tiles of 32 x 44 per CU; three such
+// views are 1,296 tiles and take the strips: 49 against 60 us)
+static int photo_cus()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 static void photo_tiling(int32_t n_views, int32_t H, int32_t W, int *tx, int *ty, int *tw, int *th, int *threads)
 {
     const long long work = (long long)n_views * 3 * H * W;
+    const char *force = getenv("T4D_PH_TILE");              // 1 / 0: force the tile / the strip kernel (tests, sweeps)
+    const long long t64 = (long long)((W + 43) / 44) * ((H + 63) / 64) * n_views * 3;
+    const long long t32 = (long long)((W + 43) / 44) * ((H + 31) / 32) * n_views * 3;
+    if (force ? atoi(force) != 0 : t32 <= 2ll * photo_cus()) {
+        *threads = 0; *tw = 44;
+        *th = (atoi(force ? force : "0") == 32 || t64 > photo_cus()) ? 32 : 64;        // (T4D_PH_TILE=32 forces the small shape)
+        *tx = (W + *tw - 1) / *tw; *ty = (H + *th - 1) / *th;
+        return;
+    }
     int best = 0;
     long long best_cost = 0;
     for (int ft = 64; ft <= 256; ft += 64) {
@@ -436,7 +626,9 @@ T4D_EXPORT int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const
     for (int i = 0; i < 11; i++) P.win[i] = g[i] / sum;
     hipStream_t stream = (hipStream_t)hip_stream;
     const dim3 grid(P.tx, P.ty, n_views * 3);
-    if (ft == 64) hipLaunchKernelGGL(k_photo_stream<64>, grid, dim3(64), 0, stream, P);
+    if (ft == 0 && P.th == 64) hipLaunchKernelGGL((k_photo_tile<64, 1024>), grid, dim3(1024), 0, stream, P);
+    else if (ft == 0) hipLaunchKernelGGL((k_photo_tile<32, 512>), grid, dim3(512), 0, stream, P);
+    else if (ft == 64) hipLaunchKernelGGL(k_photo_stream<64>, grid, dim3(64), 0, stream, P);
     else if (ft == 128) hipLaunchKernelGGL(k_photo_stream<128>, grid, dim3(128), 0, stream, P);
     else if (ft == 192) hipLaunchKernelGGL(k_photo_stream<192>, grid, dim3(192), 0, stream, P);
     else hipLaunchKernelGGL(k_photo_stream<256>, grid, dim3(256), 0, stream, P);
