@@ -611,9 +611,10 @@ def full_iteration_probe(dev, reps=5):
         params, opt, cams, gts = setup(69, 120, 512, 375, False)
         data = [{"cam": cams[i], "im": gts[i], "id": i} for i in range(24)]
 
-        def it_eager(i):
-            l, _, _ = t4d_loop.photometric_iteration(params, data[i % 24])
-            l.backward()
+        def it_eager(i):                                 # (what loop.optimise_views does per iteration: chained by hand)
+            l, _, grads, _, _ = t4d_loop.explicit_iteration(params, data[i % 24])
+            for k, gr in grads.items():
+                params[k].grad = gr
             opt.step()
             opt.zero_grad(set_to_none=True)
         for i in range(48):
@@ -675,6 +676,7 @@ def full_iteration_probe(dev, reps=5):
         out["v24_views_per_s"] = round(24e3 / min(runs), 1)
     finally:
         topo4d_amd.rasterizer._restore_sync_mode(saved)
+    out["v1_path"] = "loop.explicit_iteration: the five library calls chained by hand, no autograd (eager: as loop.optimise_views; graphed: loop.GraphedViews)"
     out["workload"] = ("params2rendervar (fused activations) -> render -> fused photometric loss (L1 + SSIM) -> backward -> fused Adam + pins; "
                        "v1: P=8280, 512x375, one camera per iteration (train.py:661-700); v24: config-2 scene, 24 cameras per launch set, view-summed gradients, one Adam step per frame")
     return out

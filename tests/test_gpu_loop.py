@@ -223,3 +223,34 @@ def test_explicit_graphed_iteration_is_the_autograd_capture_bit_for_bit():
         params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
         opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=True)
         loop.GraphedViews(params, dataset, opt, extra_loss=lambda p, rv: p['means3D'].sum() * 0, explicit=True)
+
+
+def test_explicit_eager_loop_is_the_autograd_loop_bit_for_bit():
+    """loop.optimise_views chains every iteration by hand when it can (explicit_iteration); parameters, losses and the radius
+    bookkeeping after a run must equal the autograd loop's bit for bit."""
+    from tests import util
+    from scaffold import scene
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    H, W = 64, 96
+    p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)
+    p0['cam_m'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(2)) * 0.05
+    p0['cam_c'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(3)) * 0.05
+    cams = util.to_device(scene.camera_rig(H, W, n_views=3), "cuda")
+    g = torch.Generator().manual_seed(5)
+    dataset = [{'cam': cams[i], 'im': torch.rand(3, H, W, generator=g).cuda(), 'id': i} for i in range(3)]
+    lrs = {'means3D': 1.6e-4, 'rgb_colors': 0.0025, 'unnorm_rotations': 0.001, 'logit_opacities': 0.05, 'log_scales': 0.001,
+           'cam_m': 1e-3, 'cam_c': 1e-3}
+    res = []
+    for explicit in (True, False):
+        params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15)
+        mx = torch.zeros(240, device="cuda")
+        losses = loop.optimise_views(params, dataset, opt, n_iters=9, seed=4, max_2D_radius=mx, explicit=explicit)
+        assert not opt.clear_grad and all(p.grad is None for p in params.values())
+        res.append(({k: v.detach().clone() for k, v in params.items()}, torch.stack(losses), mx))
+    (pe, le, me), (pa, la, ma) = res
+    assert torch.equal(le, la) and torch.equal(me, ma)
+    for k in pe:
+        assert torch.equal(pe[k], pa[k]), (k, (pe[k] - pa[k]).abs().max())
+    assert (pe['cam_c'] != p0['cam_c'].cuda()).any()

@@ -105,11 +105,40 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
 
 
 def optimise_views(params, dataset: List[dict], optimizer, n_iters: int, seed: int = 0, fused_loss: bool = True,
-                   extra_loss: Optional[Callable] = None, max_2D_radius: Optional[torch.Tensor] = None):
-    """train.py:661-673 for `n_iters` iterations.  Returns the list of per-iteration losses (device scalars, no sync)."""
+                   extra_loss: Optional[Callable] = None, max_2D_radius: Optional[torch.Tensor] = None,
+                   explicit: Optional[bool] = None):
+    """train.py:661-673 for `n_iters` iterations.  Returns the list of per-iteration losses (device scalars, no sync).
+    `explicit` (default: when possible - fused loss, no extra loss, a FusedAdamPins optimiser, the scale + rotation / RGB
+    parametrisation): every iteration is chained by hand (explicit_iteration) instead of going through autograd - same
+    arithmetic, a third of the host time."""
+    from .optim import FusedAdamPins
     rng = Random(seed)
     todo: list = []
     losses = []
+    can = fused_loss and extra_loss is None and isinstance(optimizer, FusedAdamPins) and all(k in params for k in _RENDER_KEYS) \
+        and ('cam_m' in params) == ('cam_c' in params) and params['means3D'].is_cuda
+    if explicit and not can:
+        raise ValueError("explicit=True needs the fused loss, no extra_loss, a FusedAdamPins optimiser and the parameters " + ", ".join(_RENDER_KEYS))
+    if can if explicit is None else explicit:
+        cam_grads, before = None, set(optimizer.clear_grad)
+        if 'cam_m' in params:
+            cam_grads = {k: torch.zeros_like(params[k]) for k in ('cam_m', 'cam_c')}
+            optimizer.clear_grad |= {g["name"] for g in optimizer.param_groups if g["params"][0] is params['cam_m'] or g["params"][0] is params['cam_c']}
+        try:
+            for _ in range(n_iters):
+                curr, todo = get_batch(todo, dataset, rng)
+                l, radius, grads, _, _ = explicit_iteration(params, curr, cam_grads)
+                for k, gr in grads.items():
+                    params[k].grad = gr
+                optimizer.step()
+                optimizer.zero_grad(set_to_none=True)
+                if max_2D_radius is not None:                      # train.py:373-375 bookkeeping
+                    seen = radius > 0
+                    max_2D_radius[seen] = torch.max(radius[seen], max_2D_radius[seen])
+                losses.append(l)
+        finally:
+            optimizer.clear_grad = before
+        return losses
     for _ in range(n_iters):
         curr, todo = get_batch(todo, dataset, rng)
         l, radius, _ = photometric_iteration(params, curr, fused_loss, extra_loss)
