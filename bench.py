@@ -652,11 +652,12 @@ def full_iteration_probe(dev, reps=5):
         params, opt, cams, gts = setup(150, 200, 512, 512, False)
         gt = torch.stack(gts)
 
-        def it_frame():
-            rv = params2rendervar_fused(params)
-            im, radii, _, _ = rasterize_views(cams, rv["means3D"], rv["means2D"], rv["opacities"], colors_precomp=rv["colors_precomp"],
-                                              scales=rv["scales"], rotations=rv["rotations"])
-            t4d_loss.photometric_loss(im, gt).sum().backward()
+        frame = [{"cam": cams[i], "im": gts[i], "id": i} for i in range(24)]
+
+        def it_frame():                                  # (loop.explicit_frame_iteration: one launch set per frame, chained by hand)
+            _, _, grads, _ = t4d_loop.explicit_frame_iteration(params, frame, gt)
+            for k, gr in grads.items():
+                params[k].grad = gr
             opt.step()
             opt.zero_grad(set_to_none=True)
         it_frame()

@@ -254,3 +254,33 @@ def test_explicit_eager_loop_is_the_autograd_loop_bit_for_bit():
     for k in pe:
         assert torch.equal(pe[k], pa[k]), (k, (pe[k] - pa[k]).abs().max())
     assert (pe['cam_c'] != p0['cam_c'].cuda()).any()
+
+
+def test_explicit_frame_iteration_equals_autograd_over_all_views():
+    """loop.explicit_frame_iteration (all cameras of a frame in one launch set, chained by hand) against the same frame through
+    autograd: params2rendervar_fused -> rasterize_views -> photometric_loss(...).sum().backward().  Losses and every gradient -
+    the camera affine's included - bit for bit."""
+    from tests import util
+    from scaffold import scene
+    from topo4d_amd import loop, loss as t4d_loss, rasterize_views
+    from topo4d_amd.boundary import params2rendervar_fused
+    H, W, V = 64, 96, 5
+    p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)
+    p0['cam_m'] = torch.randn(V, 3, generator=torch.Generator().manual_seed(2)) * 0.05
+    p0['cam_c'] = torch.randn(V, 3, generator=torch.Generator().manual_seed(3)) * 0.05
+    cams = util.to_device(scene.camera_rig(H, W, n_views=V), "cuda")
+    g = torch.Generator().manual_seed(5)
+    frame = [{'cam': cams[i], 'im': torch.rand(3, H, W, generator=g).cuda(), 'id': i} for i in range(V)]
+    params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+    l, radii, grads, _ = loop.explicit_frame_iteration(params, frame)
+    rv = params2rendervar_fused(params)
+    im, radii_a, _, _ = rasterize_views(cams, rv["means3D"], rv["means2D"], rv["opacities"], colors_precomp=rv["colors_precomp"],
+                                        scales=rv["scales"], rotations=rv["rotations"])
+    la = t4d_loss.photometric_loss(im, torch.stack([e['im'] for e in frame]), params['cam_m'], params['cam_c'])
+    la.sum().backward()
+    assert torch.equal(l, la.detach()) and torch.equal(radii, radii_a)
+    for k, gr in grads.items():
+        assert torch.equal(gr, params[k].grad), (k, (gr - params[k].grad).abs().max())
+    assert grads['cam_m'].abs().max() > 0 and grads['means3D'].abs().max() > 0
+    with pytest.raises(ValueError):
+        loop.explicit_frame_iteration(params, [frame[0], frame[2]])

@@ -104,6 +104,48 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
     return l[0], radius, grads, batch, g['means2D']
 
 
+def explicit_frame_iteration(params, frame: List[dict], gt: Optional[torch.Tensor] = None, cam_grads=None):
+    """explicit_iteration for ALL cameras of a frame in one launch set (24 views cost 0.45 ms where one costs 0.08): activations,
+    one multi-view render, one batched loss, one multi-view backward, view-summed gradients (t4d_sum_views), activation backward -
+    chained by hand, no autograd.  `frame`: the cameras' dataset entries; `gt`: their target images stacked [V,3,H,W] (stacked
+    here when None - pass it to keep that copy out of the loop).  The entries' ids must be one ascending range (rows of cam_m /
+    cam_c are passed as a view).  Returns (per-view losses [V], radii [V,P], grads of the loss SUMMED over the views, ViewBatch)."""
+    from . import rasterizer as R
+    cams = [e['cam'] for e in frame]
+    V = len(cams)
+    dev = params['means3D'].device
+    H, W, smod, deg = R._check_common(cams)
+    d = lambda k: params[k].detach()
+    ur = d('unnorm_rotations')
+    rot, op, sc = activate_forward(ur, d('logit_opacities'), d('log_scales'))
+    batch = R.ViewBatch(R.pack_views(cams, dev), H, W, smod, deg)
+    im, radii, _, _ = batch.forward(d('means3D'), op, sc, rot, colors_precomp=d('rgb_colors'))
+    if gt is None:
+        gt = torch.stack([e['im'] for e in frame])
+    cm = cc = dcm = dcc = None
+    if 'cam_m' in params:
+        i0 = frame[0]['id']
+        if [e['id'] for e in frame] != list(range(i0, i0 + V)):
+            raise ValueError("explicit_frame_iteration: the frame's camera ids must be one ascending range")
+        cm, cc = d('cam_m')[i0:i0 + V], d('cam_c')[i0:i0 + V]
+        if cam_grads is not None:
+            dcm, dcc = cam_grads['cam_m'][i0:i0 + V], cam_grads['cam_c'][i0:i0 + V]
+    l, d_im, dcm, dcc = t4d_loss.photometric_loss_raw(im, gt, cm, cc, dcm, dcc)
+    g = R._sum_views(batch.backward(d_im), V, need_means2D=False)
+    d_ur, d_lo, d_ls = activate_backward(ur, op, sc, g['rotations'], g['opacities'], g['scales'])
+    grads = {'means3D': g['means3D'], 'rgb_colors': g['colors_precomp'], 'unnorm_rotations': d_ur, 'logit_opacities': d_lo,
+             'log_scales': d_ls}
+    if cm is not None:
+        if cam_grads is not None:
+            grads['cam_m'], grads['cam_c'] = cam_grads['cam_m'], cam_grads['cam_c']
+        else:
+            for k, rows in (('cam_m', dcm), ('cam_c', dcc)):
+                full = torch.zeros_like(params[k])
+                full[i0:i0 + V] = rows
+                grads[k] = full
+    return l, radii, grads, batch
+
+
 def optimise_views(params, dataset: List[dict], optimizer, n_iters: int, seed: int = 0, fused_loss: bool = True,
                    extra_loss: Optional[Callable] = None, max_2D_radius: Optional[torch.Tensor] = None,
                    explicit: Optional[bool] = None):
