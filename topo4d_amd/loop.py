@@ -77,7 +77,8 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
     ur = d('unnorm_rotations')
     rot, op, sc = activate_forward(ur, d('logit_opacities'), d('log_scales'))
     batch = R.ViewBatch(R.pack_views([cam], dev), int(cam.image_height), int(cam.image_width), float(cam.scale_modifier),
-                        int(cam.sh_degree), debug=bool(cam.debug), prefiltered=bool(cam.prefiltered), cam_key=id(cam))
+                        int(cam.sh_degree), debug=bool(cam.debug), prefiltered=bool(cam.prefiltered), cam_key=id(cam),
+                        sync_mode=R.get_sync_mode(drop_in=True))      # the mode a differentiated drop-in call runs ("auto" by default)
     batch.flat_grads = True                               # the drop-in's shapes: no view axis
     batch.status_sink = status_sink                       # (lazy mode: pinned host words for the forward's status block)
     im, radius, _, _ = batch.forward(d('means3D'), op, sc, rot, colors_precomp=d('rgb_colors'))
