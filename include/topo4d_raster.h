@@ -70,9 +70,15 @@ enum {
     T4D_FLAG_SHORT_BINS = 32u, /* forward: ... and that none exceeds 512 pairs (the one-pass ranking sort): a small launch then
                                   sorts every bin inside the render workgroup of its tile instead of launching a sort kernel.
                                   A speed hint like the one above */
-    T4D_FLAG_LONG_LISTS = 64u  /* forward: the caller knows that some tile list exceeds 1,024 pairs: launches of up to 24 x CUs
+    T4D_FLAG_LONG_LISTS = 64u, /* forward: the caller knows that some tile list exceeds 1,024 pairs: launches of up to 24 x CUs
                                   tiles (instead of 12 x) run the latency build of the forward, which such a list bounds.
                                   A speed hint */
+    T4D_FLAG_RAW_PARAMS = 128u /* forward AND backward of a call: `rotations`, `opacities`, `scales` are Topo4D's optimiser
+                                  parameters - un-normalised quaternions, logit opacities, log scales (helpers.py:95-97) - the
+                                  library applies F.normalize / sigmoid / exp itself (the arithmetic of t4d_activate_forward), and
+                                  the backward returns dL/d(unnorm_rotations), dL/d(logit_opacities), dL/d(log_scales) in
+                                  dL_drotations, dL_dopacities, dL_dscales (per view; the arithmetic of t4d_activate_backward):
+                                  params2rendervar and its autograd without a launch of their own */
 };
 
 typedef struct T4DProblem {

@@ -284,3 +284,50 @@ def test_explicit_frame_iteration_equals_autograd_over_all_views():
     assert grads['cam_m'].abs().max() > 0 and grads['means3D'].abs().max() > 0
     with pytest.raises(ValueError):
         loop.explicit_frame_iteration(params, [frame[0], frame[2]])
+
+
+def test_raw_parameter_mode_of_the_rasterizer_is_params2rendervar_bit_for_bit():
+    """T4D_FLAG_RAW_PARAMS (ViewBatch.raw_params): the rasterizer takes un-normalised quaternions, logit opacities and log scales
+    (helpers.py:95-97) and returns their gradients.  Against t4d_activate_forward -> rasterizer -> t4d_activate_backward per
+    view: outputs, radii and every gradient bit for bit - invisible Gaussians (zeros) and a zero quaternion (the eps-clamped
+    branch of F.normalize) included."""
+    from tests import util
+    from scaffold import scene
+    from topo4d_amd import ViewBatch, pack_views
+    from topo4d_amd.boundary import activate_backward, activate_forward
+    H, W, V = 96, 80, 3
+    p = scene.make_gaussians(14, 22, opacity="B", seed=4)
+    P = p['means3D'].shape[0]
+    g = torch.Generator().manual_seed(8)
+    p['unnorm_rotations'] = p['unnorm_rotations'] * (0.3 + 2 * torch.rand(P, 1, generator=g))
+    p['unnorm_rotations'][5] = 0.0
+    p['log_scales'] = p['log_scales'] + torch.randn(P, 3, generator=g) * 0.3
+    p['means3D'][7] = torch.tensor([0.0, 0.0, 50.0])          # far outside every frustum
+    cams = util.to_device(scene.camera_rig(H, W, n_views=V), "cuda")
+    dev = torch.device("cuda")
+    ur, lo, ls = (p[k].cuda().contiguous() for k in ('unnorm_rotations', 'logit_opacities', 'log_scales'))
+    m3, rgb = p['means3D'].cuda(), p['rgb_colors'].cuda()
+    dc = torch.randn(V, 3, H, W, generator=g).cuda()
+    views = pack_views(cams, dev)
+    # route 1: separate activation kernels
+    rot, op, sc = activate_forward(ur, lo, ls)
+    b1 = ViewBatch(views, H, W)
+    o1 = b1.forward(m3, op, sc, rot, colors_precomp=rgb)
+    g1 = b1.backward(dc)
+    # route 2: raw parameters
+    b2 = ViewBatch(views, H, W)
+    b2.raw_params = True
+    o2 = b2.forward(m3, lo, ls, ur, colors_precomp=rgb)
+    g2 = b2.backward(dc)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for k in ('means3D', 'means2D', 'colors_precomp'):
+        assert torch.equal(g1[k], g2[k]), k
+    assert (o1[1] > 0).any() and (o1[1][:, 7] == 0).all()
+    for v in range(V):
+        d_ur, d_lo, d_ls = activate_backward(ur, op, sc, g1['rotations'][v].contiguous(), g1['opacities'][v].contiguous(),
+                                             g1['scales'][v].contiguous())
+        assert torch.equal(d_ur, g2['rotations'][v]), v
+        assert torch.equal(d_lo, g2['opacities'][v]), v
+        assert torch.equal(d_ls, g2['scales'][v]), v
+    assert torch.isfinite(g2['rotations']).all() and g2['scales'].abs().max() > 0 and (g2['opacities'][:, 7] == 0).all()

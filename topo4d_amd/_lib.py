@@ -23,6 +23,7 @@ T4D_OK, T4D_ERR_ARG, T4D_ERR_HIP, T4D_ERR_PAIR_OVERFLOW, T4D_ERR_STATE_SIZE = 0,
 T4D_FLAG_CHECKED, T4D_FLAG_DEBUG_SYNC, T4D_FLAG_PREFILTERED, T4D_FLAG_ASYNC_STATUS, T4D_FLAG_NO_LONG_BINS = 1, 2, 4, 8, 16
 T4D_FLAG_SHORT_BINS = 32
 T4D_FLAG_LONG_LISTS = 64
+T4D_FLAG_RAW_PARAMS = 128
 
 # every symbol include/topo4d_raster.h declares (tests/test_abi.py checks header <-> this list <-> the .so)
 EXPORTS = (

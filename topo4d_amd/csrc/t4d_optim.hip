@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "../../include/topo4d_raster.h"
+#include "t4d_activations.h"
 
 #define T4D_EXPORT extern "C" __attribute__((visibility("default")))
 int t4d_internal_fail(int code, const char *fmt, const char *a);
@@ -188,19 +189,15 @@ T4D_EXPORT int t4d_dense_interpolate(const float *attribute, const int32_t *quad
 // F.normalize(x, p=2, dim=1, eps=1e-12) = x / max(||x||_2, eps).
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr float kNormEps = 1e-12f;
-
 __global__ __launch_bounds__(256) void k_activate_fwd(long long P, const float4 *unnorm_rot, const float *logit_op, const float *log_scale,
                                                       float4 *rot, float *op, float *scale)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const float4 q = unnorm_rot[i];
-    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), kNormEps);
-    rot[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
-    op[i] = 1.0f / (1.0f + expf(-logit_op[i]));
+    rot[i] = t4d_act_normalize(unnorm_rot[i]);
+    op[i] = t4d_act_sigmoid(logit_op[i]);
 #pragma unroll
-    for (int k = 0; k < 3; k++) scale[3 * i + k] = expf(log_scale[3 * i + k]);
+    for (int k = 0; k < 3; k++) scale[3 * i + k] = t4d_act_exp(log_scale[3 * i + k]);
 }
 
 __global__ __launch_bounds__(256) void k_activate_bwd(long long P, const float4 *unnorm_rot, const float *op, const float *scale,
@@ -209,26 +206,11 @@ __global__ __launch_bounds__(256) void k_activate_bwd(long long P, const float4 
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    if (g_unnorm) {
-        const float4 q = unnorm_rot[i];
-        const float4 g = g_rot ? g_rot[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        if (nn > kNormEps) {                             // y = x / n:  dx = (g - y (y . g)) / n
-            const float inv = 1.0f / nn;
-            const float4 y = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-            const float yg = y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
-            g_unnorm[i] = make_float4((g.x - y.x * yg) * inv, (g.y - y.y * yg) * inv, (g.z - y.z * yg) * inv, (g.w - y.w * yg) * inv);
-        } else {                                         // clamped denominator: y = x / eps
-            g_unnorm[i] = make_float4(g.x / kNormEps, g.y / kNormEps, g.z / kNormEps, g.w / kNormEps);
-        }
-    }
-    if (g_logit) {
-        const float s = op[i];
-        g_logit[i] = g_op ? g_op[i] * s * (1.0f - s) : 0.f;
-    }
+    if (g_unnorm) g_unnorm[i] = t4d_act_normalize_bwd(unnorm_rot[i], g_rot ? g_rot[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+    if (g_logit) g_logit[i] = g_op ? t4d_act_sigmoid_bwd(op[i], g_op[i]) : 0.f;
     if (g_log_scale) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) g_log_scale[3 * i + k] = g_scale ? g_scale[3 * i + k] * scale[3 * i + k] : 0.f;
+        for (int k = 0; k < 3; k++) g_log_scale[3 * i + k] = g_scale ? t4d_act_exp_bwd(scale[3 * i + k], g_scale[3 * i + k]) : 0.f;
     }
 }
 }  // namespace

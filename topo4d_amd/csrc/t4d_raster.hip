@@ -46,6 +46,7 @@
 
 #include "../../include/t4d_config.h"
 #include "../../include/topo4d_raster.h"
+#include "t4d_activations.h"
 
 #define T4D_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -182,6 +183,7 @@ struct KP {
     uint32_t *view_total, *view_cursor, *tile_count, *bucket_fill, *tile_off, *chunk_sum, *order, *pair_off, *pair_rank;
     int n_chunks;                    // scan chunks per view = ceil(T / kScanChunk)
     int long_bins_elsewhere;         // 1: k_sort_long runs behind k_sort_tiles and takes the bins longer than kSortLdsCap
+    int raw_params;                  // T4D_FLAG_RAW_PARAMS: rotations / opacities / scales are the optimiser's raw parameters
     uint4 *items;
     float2 *xy;
     float *depth;
@@ -540,6 +542,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.T = kp.gx * kp.gy;
     kp.deg = p.sh_degree; kp.M = p.sh_coeffs;
     kp.scale_modifier = p.scale_modifier;
+    kp.raw_params = (p.flags & T4D_FLAG_RAW_PARAMS) ? 1 : 0;
     kp.cap = (uint32_t)p.pair_capacity;
     {
         const uint32_t n_wg = (uint32_t)((p.P + kBlock - 1) / kBlock);

@@ -41,7 +41,14 @@ __device__ __forceinline__ void preprocess_body(const KP &kp, const uint32_t gb,
             sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
             q = reinterpret_cast<const float4 *>(kp.rotations)[g];
         }
-        const float opacity = kp.opacities[g];
+        float opacity = kp.opacities[g];
+        if (kp.raw_params) {                             // T4D_FLAG_RAW_PARAMS: the optimiser's parameters (helpers.py:95-97)
+            opacity = t4d_act_sigmoid(opacity);
+            if (!kp.cov3D_precomp) {
+                sc[0] = t4d_act_exp(sc[0]); sc[1] = t4d_act_exp(sc[1]); sc[2] = t4d_act_exp(sc[2]);
+                q = t4d_act_normalize(q);
+            }
+        }
         int radius = 0;
         const float pvz = view[2] * mean[0] + view[6] * mean[1] + view[10] * mean[2] + view[14];
         if (pvz > T4D_NEAR_CULL_Z) {

@@ -64,6 +64,11 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
         sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
         q = reinterpret_cast<const float4 *>(kp.rotations)[g];
     }
+    const float4 q_raw = q;
+    if (kp.raw_params && !kp.cov3D_precomp) {            // T4D_FLAG_RAW_PARAMS: activate as the forward did
+        sc[0] = t4d_act_exp(sc[0]); sc[1] = t4d_act_exp(sc[1]); sc[2] = t4d_act_exp(sc[2]);
+        q = t4d_act_normalize(q);
+    }
     // A forward whose pair arena overflowed (possible only without T4D_FLAG_CHECKED) left tile lists truncated and pair
     // records unwritten: its backward returns ZERO gradients for every view instead of sums over uninitialised scratch.
     const bool truncated = flag != 0u;
@@ -187,6 +192,16 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
         }
     }
 
+    if (kp.raw_params && radius > 0) {                   // ... and return the gradients of the raw parameters (t4d_activate_backward's
+        // arithmetic; an invisible Gaussian keeps its zeros - the forward stored nothing for it)
+        gop = t4d_act_sigmoid_bwd(cq.w, gop);            // (conic_opacity.w is the activated opacity the forward stored)
+        if (!kp.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) gsc[k] = t4d_act_exp_bwd(sc[k], gsc[k]);
+            const float4 gr = t4d_act_normalize_bwd(q_raw, make_float4(gq[0], gq[1], gq[2], gq[3]));
+            gq[0] = gr.x; gq[1] = gr.y; gq[2] = gr.z; gq[3] = gr.w;
+        }
+    }
     kp.dL_dmeans3D[vg * 3] = gm[0]; kp.dL_dmeans3D[vg * 3 + 1] = gm[1]; kp.dL_dmeans3D[vg * 3 + 2] = gm[2];
     kp.dL_dmeans2D[vg * 3] = g2x; kp.dL_dmeans2D[vg * 3 + 1] = g2y; kp.dL_dmeans2D[vg * 3 + 2] = 0.f;
     kp.dL_dopacities[vg] = gop;

@@ -61,8 +61,9 @@ _RENDER_KEYS = ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 
 
 
 def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
-    """photometric_iteration + loss.backward() WITHOUT autograd: the same launches - t4d_activate_forward, t4d_rasterize_forward,
-    t4d_photometric_loss, t4d_rasterize_backward, t4d_activate_backward - chained by hand, and none of the launches autograd
+    """photometric_iteration + loss.backward() WITHOUT autograd: t4d_rasterize_forward, t4d_photometric_loss,
+    t4d_rasterize_backward chained by hand - the activations and their backward inside the rasterizer (T4D_FLAG_RAW_PARAMS:
+    the arithmetic of t4d_activate_forward / t4d_activate_backward, no launch of their own) - and none of the launches autograd
     puts around them (the zeros + 0 of means2D, ones_like for the root, a fill and a copy for every `[cid]` / `[0]` it
     differentiates through, the multiplication of dL/dim by a cotangent of one: nine launches of 4-5 us per iteration, a third
     of a 148 us graphed iteration).  For the precomputed-RGB, scale + rotation parametrisation of train.py:303-315 with the
@@ -74,14 +75,16 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
     cam = curr_data['cam']
     dev = params['means3D'].device
     d = lambda k: params[k].detach()
-    ur = d('unnorm_rotations')
-    rot, op, sc = activate_forward(ur, d('logit_opacities'), d('log_scales'))
     batch = R.ViewBatch(R.pack_views([cam], dev), int(cam.image_height), int(cam.image_width), float(cam.scale_modifier),
                         int(cam.sh_degree), debug=bool(cam.debug), prefiltered=bool(cam.prefiltered), cam_key=id(cam),
                         sync_mode=R.get_sync_mode(drop_in=True))      # the mode a differentiated drop-in call runs ("auto" by default)
     batch.flat_grads = True                               # the drop-in's shapes: no view axis
     batch.status_sink = status_sink                       # (lazy mode: pinned host words for the forward's status block)
-    im, radius, _, _ = batch.forward(d('means3D'), op, sc, rot, colors_precomp=d('rgb_colors'))
+    # T4D_FLAG_RAW_PARAMS: the rasterizer takes the optimiser's parameters as they are and returns their gradients - the
+    # arithmetic of t4d_activate_forward / t4d_activate_backward inside the binning kernel and the per-Gaussian backward
+    batch.raw_params = True
+    im, radius, _, _ = batch.forward(d('means3D'), d('logit_opacities'), d('log_scales'), d('unnorm_rotations'),
+                                     colors_precomp=d('rgb_colors'))
     cid = curr_data['id']
     cm = cc = dcm = dcc = None
     if 'cam_m' in params:
@@ -91,9 +94,8 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None):
     gt = curr_data['im']
     l, d_im, dcm, dcc = t4d_loss.photometric_loss_raw(im[None], gt[None] if gt.is_contiguous() else gt.contiguous()[None], cm, cc, dcm, dcc)
     g = batch.backward(d_im)
-    d_ur, d_lo, d_ls = activate_backward(ur, op, sc, g['rotations'], g['opacities'], g['scales'])
-    grads = {'means3D': g['means3D'], 'rgb_colors': g['colors_precomp'], 'unnorm_rotations': d_ur, 'logit_opacities': d_lo,
-             'log_scales': d_ls}
+    grads = {'means3D': g['means3D'], 'rgb_colors': g['colors_precomp'], 'unnorm_rotations': g['rotations'],
+             'logit_opacities': g['opacities'], 'log_scales': g['scales']}
     if cm is not None:
         if cam_grads is not None:
             grads['cam_m'], grads['cam_c'] = cam_grads['cam_m'], cam_grads['cam_c']

@@ -376,6 +376,10 @@ class ViewBatch:
         # { overflow | pairs needed << 32, total pairs } - a one-view launch's binning kernel writes them itself, so a captured
         # iteration (loop.GraphedViews) needs no copy node to keep the status of its forward
         self.status_sink = None
+        # T4D_FLAG_RAW_PARAMS: `rotations`, `opacities`, `scales` of forward() are Topo4D's optimiser parameters (un-normalised
+        # quaternions, logits, log scales - helpers.py:95-97); the library activates them itself and backward() returns the
+        # gradients with respect to them
+        self.raw_params = False
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def _flags(self, P: int, checked: bool) -> int:
@@ -386,6 +390,8 @@ class ViewBatch:
             flags |= T4D_FLAG_DEBUG_SYNC
         if self.prefiltered:
             flags |= T4D_FLAG_PREFILTERED
+        if self.raw_params:
+            flags |= _lib.T4D_FLAG_RAW_PARAMS
         # tile lists of this scene size stayed well below the LDS sort buffer (2048) so far: skip the long-bin sort launch
         # (a speed hint only - see include/topo4d_raster.h)
         longest = _LONGEST_BIN.get((self.device.index, P, self.H, self.W))
