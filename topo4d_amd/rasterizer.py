@@ -399,7 +399,8 @@ class ViewBatch:
             flags |= _lib.T4D_FLAG_LONG_LISTS     # some tile list bounds a small launch: the latency forward for up to 24 x CUs tiles
         if longest is not None and longest <= 1536:
             flags |= T4D_FLAG_NO_LONG_BINS
-            if longest <= 448:            # ... and below the one-pass ranking sort (512): small launches sort inside the render kernel
+            if longest <= 500:            # ... and below the one-pass ranking sort (512; a bin that outgrows it is still sorted
+                                          # correctly, by the slower LDS merge): small launches sort inside the render kernel
                 flags |= _lib.T4D_FLAG_SHORT_BINS
         return flags
 
