@@ -155,3 +155,28 @@ def test_sync_mode_save_restore_leaves_no_trace():
         assert topo4d_amd.get_sync_mode(drop_in=True) == "auto"      # the drop-in's default is the default again
     finally:
         rasterizer._restore_sync_mode(saved)
+
+
+def test_hand_chained_iteration_has_no_cpu_path_and_checks_its_arguments():
+    """loop.explicit_iteration / explicit_frame_iteration / optimise_views(explicit=True) and the raw entry points they use fail
+    loudly on CPU tensors (no fallback), and refuse what they cannot chain by hand."""
+    from scaffold import scene
+    from topo4d_amd import loop, loss, boundary
+    from topo4d_amd.optim import FusedAdamPins
+    p = {k: torch.nn.Parameter(v) for k, v in scene.make_gaussians(4, 6, opacity="A", seed=0).items()}
+    cam = _cam()
+    data = {"cam": cam, "im": torch.zeros(3, int(cam.image_height), int(cam.image_width)), "id": 0}
+    with pytest.raises(RuntimeError, match="no CPU path|GPU only"):
+        loop.explicit_iteration(p, data)
+    with pytest.raises(RuntimeError, match="no CPU path|GPU only"):
+        loop.explicit_frame_iteration(p, [data])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        loss.photometric_loss_raw(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        boundary.activate_forward(p["unnorm_rotations"].detach(), p["logit_opacities"].detach(), p["log_scales"].detach())
+    groups = [{"params": [v], "name": k, "lr": 1e-3} for k, v in p.items()]
+    with pytest.raises(ValueError, match="explicit=True needs"):           # CPU parameters cannot be chained by hand
+        loop.optimise_views(p, [data], FusedAdamPins(groups), n_iters=1, explicit=True)
+    with pytest.raises(ValueError, match="explicit=True needs"):           # nor can an extra loss term
+        loop.optimise_views(p, [data], FusedAdamPins(groups), n_iters=1, extra_loss=lambda a, b: 0.0, explicit=True)
+    assert _lib.T4D_FLAG_RAW_PARAMS == 128 and _lib.T4D_ADAM_CLEAR_GRAD == 1
