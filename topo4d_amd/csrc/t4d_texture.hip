@@ -43,6 +43,9 @@ struct Tri {                                // 80 bytes = five 16-byte words: th
 };
 static_assert(sizeof(Tri) == 80, "Tri must stay five float4 words");
 constexpr int kScanChunk = 1024;
+#ifndef T4D_TEX_ABL
+#define T4D_TEX_ABL 0                // timing experiments only (results wrong): 1 = no per-triangle texel loop, 2 = the write-out stores one float per texel
+#endif
 
 struct TexP {
     const float *vertices;
@@ -315,6 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
         return;
     }
     const uint32_t off = P.bin_off[b];
+    // (only the tiles along the image's edge hold texels of the 2-pixel border ring: the others skip the four compares per texel)
+    const bool tile_border = tx0 < 2 || ty0 < 2 || tx0 + kTile > P.w - 3 || ty0 + kTile > P.h - 3;
     for (int e = tid; e < kTile * kTile; e += kBlock) {           // the caller's depth buffer for this tile: read once, tested from LDS
         s_key[e] = 0ull;
         if (!FRESH) {
@@ -361,17 +366,20 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
             }
             __syncthreads();
         }
-        for (int k = wave; k < cnt; k += kBlock / 64) {           // wave-uniform: one record per wave at a time
+        for (int k = wave; k < ((T4D_TEX_ABL & 1) ? 0 : cnt); k += kBlock / 64) {           // wave-uniform: one record per wave at a time
             const Tri t = s_tri[k];
             const int x_lo = max(t.x_min, tx0), x_hi = min(t.x_max, rx_hi), y_lo = max(t.y_min, ry_lo), y_hi = min(t.y_max, ry_hi);
             const int rw = x_hi - x_lo + 1, rh = y_hi - y_lo + 1;
             if (rw <= 0 || rh <= 0) continue;
             const int npx = rw * rh;
             const uint32_t tag = fast ? (uint32_t)k : (uint32_t)t.idx;     // sorted slot or triangle index: lower wins on equal depth
+            // p / rw without an integer division (~25 instructions per texel, a fifth of this loop): rw <= 32 and p < 1,024, so the
+            // 16-bit fixed-point reciprocal m >= 65536 / rw with m rw - 65536 <= rw gives the exact quotient (p (m rw - 65536) < 65536)
+            const uint32_t m_rw = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)rw)) + 1u;
             for (int p = lane; p < npx; p += 64) {
-                const int dy = p / rw, x = x_lo + (p - dy * rw), y = y_lo + dy;
+                const int dy = (int)(((uint32_t)p * m_rw) >> 16), x = x_lo + (p - dy * rw), y = y_lo + dy;
                 const float px = (float)x, py = (float)y;
-                const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;      // mesh_core.cpp:211
+                const bool border = tile_border && (px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3);      // mesh_core.cpp:211
                 const TriEval ev = eval_texel(t, px, py, border);
                 // `pd > depth_buffer` against the caller's buffer first (also drops NaN); later rivals meet in the LDS maximum
                 const float have = FRESH ? kFreshDepth : s_depth[(y - ty0) * kTile + (x - tx0)];
@@ -401,11 +409,17 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
             }
             const int slot = (int)~(uint32_t)key;
             const float px = (float)x, py = (float)y;
-            const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;
+            const bool border = tile_border && (px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3);
             const TriEval ev = eval_texel(s_tri[slot], px, py, border);
+#if T4D_TEX_ABL & 2
+            float acc = ev.pd;
+            for (int k = 0; k < P.c; k++) acc += ev.w0 * s_col[slot][0][k] + ev.w1 * s_col[slot][1][k] + ev.w2 * s_col[slot][2][k];
+            P.depth[o] = acc;
+#else
             for (int k = 0; k < P.c; k++)
                 P.image[o * P.c + k] = ev.w0 * s_col[slot][0][k] + ev.w1 * s_col[slot][1][k] + ev.w2 * s_col[slot][2][k];
             P.depth[o] = ev.pd;
+#endif
         }
         return;
     }
