@@ -10,6 +10,21 @@ from __future__ import annotations
 import torch
 
 
+def _check_raw(**tensors):
+    """The raw entry points hand data pointers to the library: contiguous float32 HIP tensors only ([P,4] / [P,1] / [P,3])."""
+    P = None
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("params2rendervar_fused runs on the GPU only (no CPU fallback)")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous float32 tensor")
+        P = t.shape[0] if P is None else P
+        if t.shape[0] != P:
+            raise ValueError(f"{name} holds {t.shape[0]} rows, expected {P}")
+
+
 def activate_forward(unnorm_rotations, logit_opacities, log_scales):
     """rotations, opacities, scales = normalize(unnorm_rotations), sigmoid(logit_opacities), exp(log_scales) in ONE launch
     (t4d_activate_forward); no autograd - contiguous fp32 HIP tensors in, new tensors out."""
@@ -20,6 +35,7 @@ def activate_forward(unnorm_rotations, logit_opacities, log_scales):
     if dev.type != "cuda":
         raise RuntimeError("params2rendervar_fused runs on the GPU only (no CPU fallback)")
     ur, lo, ls = unnorm_rotations, logit_opacities, log_scales
+    _check_raw(ur=ur, lo=lo, ls=ls)
     rot, op, sc = torch.empty_like(ur), torch.empty_like(lo), torch.empty_like(ls)
     p = lambda t: C.c_void_p(t.data_ptr())
     rc = lib.t4d_activate_forward(ur.shape[0], p(ur), p(lo), p(ls), p(rot), p(op), p(sc), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
@@ -36,6 +52,7 @@ def activate_backward(unnorm_rotations, opacities, scales, g_rot, g_op, g_sc, ne
     lib = _lib.load()
     ur, op, sc = unnorm_rotations, opacities, scales
     dev = ur.device
+    _check_raw(ur=ur, op=op, sc=sc, g_rot=g_rot, g_op=g_op, g_sc=g_sc)
     d_ur = torch.empty_like(ur) if need[0] else None
     d_lo = torch.empty_like(op) if need[1] else None
     d_ls = torch.empty_like(sc) if need[2] else None

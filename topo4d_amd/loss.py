@@ -64,6 +64,12 @@ def photometric_loss_raw(im, gt, cam_m=None, cam_c=None, d_cam_m=None, d_cam_c=N
         raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
     V, _, H, W = im.shape
     dev = im.device
+    for name, t, shape in (("im", im, (V, 3, H, W)), ("gt", gt, (V, 3, H, W)), ("cam_m", cam_m, (V, 3)), ("cam_c", cam_c, (V, 3)),
+                           ("d_cam_m", d_cam_m, (V, 3)), ("d_cam_c", d_cam_c, (V, 3))):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or tuple(t.shape) != shape):
+            raise ValueError(f"photometric_loss_raw: {name} must be a contiguous float32 tensor of shape {shape} on {dev}")
+    if (cam_m is None) != (cam_c is None) or (d_cam_m is None) != (d_cam_c is None):
+        raise ValueError("photometric_loss_raw: cam_m / cam_c (and their gradient buffers) come in pairs")
     loss = torch.empty(V, dtype=torch.float32, device=dev)
     d_im = torch.empty_like(im)
     have_cam = cam_m is not None
