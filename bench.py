@@ -581,6 +581,88 @@ def dense_1m_probe(dev, reps=5):
             "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs), "kernels_us": kern}
 
 
+def loss_probe(dev):
+    """Row f1: the fused photometric loss (t4d_photometric_loss: per-camera affine + 0.8 L1 + 0.2 (1-SSIM), forward AND gradient,
+    train.py:310,315) - kernel time by HIP events on the launch stream around back-to-back library calls, its own roofline.
+    Algorithmic bytes per pixel and channel: read im + gt, write dL/dim = 12 B (36 B per pixel)."""
+    import ctypes as C
+    from topo4d_amd import _lib
+    lib = _lib.load()
+
+    def raw(V_, H_, W_, reps):
+        g = torch.Generator().manual_seed(V_ + H_)
+        a = torch.rand(V_, 3, H_, W_, generator=g).to(dev)
+        b = torch.rand(V_, 3, H_, W_, generator=g).to(dev)
+        cm, cc = (torch.randn(V_, 3, generator=g) * 0.1).to(dev), (torch.randn(V_, 3, generator=g) * 0.05).to(dev)
+        l, d, dm, dcc = torch.empty(V_, device=dev), torch.empty_like(a), torch.empty_like(cm), torch.empty_like(cc)
+        nb = lib.t4d_photometric_scratch_bytes(V_, H_, W_)
+        sc = torch.empty(nb, dtype=torch.uint8, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        call = lambda: lib.t4d_photometric_loss(V_, H_, W_, p(a), p(b), p(cm), p(cc), None, p(l), p(d), p(dm), p(dcc), p(sc), nb, st)
+        for _ in range(5):
+            if call() != 0:
+                raise RuntimeError(_lib.last_error())
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            t = 1e3 * e0.elapsed_time(e1) / reps
+            best = t if best is None or t < best else best
+        alg = V_ * 3 * H_ * W_ * 12
+        return {"kernel_us": round(best, 1), "alg_bytes": alg, "achieved_GBs": round(alg / best / 1e3, 1),
+                "frac": round(alg / best / 1e3 / PEAK_HBM_GBS, 4)}
+    return {"workload": "t4d_photometric_loss: camera affine + 0.8 L1 + 0.2 (1 - SSIM 11x11), loss AND dL/dim, dL/dcam_m, dL/dcam_c in one call",
+            "24x512x512": raw(24, 512, 512, 40), "1x512x375": raw(1, 512, 375, 100), "24x2048x2048": raw(24, 2048, 2048, 4),
+            "roofline": {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "measured_limiter": "vector-ALU issue (154 multiply-adds per pixel and channel: two separable 11-tap passes over 4 + 3 maps)"},
+            "timing": "HIP events on the launch stream around back-to-back calls, min of 5 runs (the kernels + the final-sum launch)"}
+
+
+def bake_probe(dev, cpu=True, res=8192, n=1025):
+    """BASELINE config 5: the 8192^2 texture bake (t4d_texture_bake behind topo4d_amd.texture.render_colors = the reference's
+    face3d render_colors -> _render_colors_core, helpers.py:953-960, mesh_core.cpp:169-234) of a UV mesh of ~10^6 vertices /
+    2.1 M triangles.  Algorithmic bytes: 16 B per texel (3 colour floats + the depth buffer) + the inputs read once."""
+    from oracle import texture_oracle as TX
+    from tests.test_texture_oracle import uv_mesh
+    from topo4d_amd import texture
+    verts, tris, colors = uv_mesh(n, res, res, seed=0)
+    tris = np.sort(tris.view([("a", np.int32), ("b", np.int32), ("c", np.int32)]), order=["a"], axis=0).view(np.int32)   # mesh order
+    v, t, c = (torch.as_tensor(x).to(dev) for x in (verts, tris, colors))
+    img = texture.render_colors(v, t, c, res, res)          # warm-up + pair capacity
+    torch.cuda.synchronize(dev)
+    runs = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(5):
+            img = texture.render_colors(v, t, c, res, res)
+        torch.cuda.synchronize(dev)
+        runs.append(1e3 * (time.perf_counter() - t0) / 5)
+    ms = min(runs)
+    alg = res * res * 16 + verts.nbytes + tris.nbytes + colors.nbytes
+    out = {"workload": f"{res}x{res} texels, {int(tris.shape[0])} triangles, {int(verts.shape[0])} vertices, 3 channels; output + depth "
+                       "buffer allocation and fill, binning and render included, inputs resident in HBM",
+           "ms": round(ms, 3), "ms_runs": [round(x, 3) for x in runs], "texels_per_s": round(res * res / ms * 1e3, 1),
+           "alg_bytes": int(alg),
+           "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(alg / ms / 1e6 / PEAK_HBM_GBS, 4)}}
+    if cpu:
+        t0 = time.perf_counter()
+        ref = TX.render_colors_cpu(verts, tris, colors, res, res)
+        sec = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(res * res / sec, 1), "unit": "texels/s", "seconds": round(sec, 3), "cores": 1,
+                               "kind": "reference" if TX.have_ref() else "port",
+                               "sample": "the same full mesh, one run (the reference's code is single-threaded by construction)"}
+        out["bit_identical_to_cpu"] = bool(np.array_equal(img.cpu().numpy(), ref))
+        out["speedup"] = round(sec * 1e3 / ms, 1)
+    return out
+
+
 def full_iteration_probe(dev, reps=5):
     """The whole optimisation iteration around the rasterizer (train.py:661-700): activations -> render -> photometric loss ->
     backward -> Adam + region pins, on the fused pieces.  V = 1 (the reference's schedule: one camera per iteration, P = 8,280,
@@ -877,7 +959,7 @@ def main():
         del wv
 
     # ---- side measurements on one GPU ----
-    scenario_b = single_view = drop_in = small_v = forecast = c4 = dense_1m = full_iteration = None
+    scenario_b = single_view = drop_in = small_v = forecast = c4 = dense_1m = full_iteration = loss_k = bake = None
     if world == 1 and not args.no_extras:
         def guarded(fn, *a):
             try:                        # side measurements must never take the headline number down with them
@@ -910,6 +992,10 @@ def main():
             torch.cuda.empty_cache()
             dense_1m = guarded(dense_1m_probe, dev)
             torch.cuda.empty_cache()
+            loss_k = guarded(loss_probe, dev)
+            torch.cuda.empty_cache()
+            bake = guarded(bake_probe, dev, not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
 
     if rank == 0:
         views_total = views_per_step_job * my_steps
@@ -939,7 +1025,7 @@ def main():
                        "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "frames_in_flight": wl.F},
             "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "small_v": small_v,
             "forecast": forecast, "view_sharded": view_sharded, "drop_in": drop_in, "full_iteration": full_iteration, "c4": c4,
-            "dense_1m": dense_1m, "sequential": sequential,
+            "dense_1m": dense_1m, "loss": loss_k, "bake_8192": bake, "sequential": sequential,
             ("weak" if (args.scaling == "strong" and not by_views) else "strong"): other,
             "dist_backend": (dist.get_backend() if dist is not None else None),
         }

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define T4D_ABI_VERSION 2
+#define T4D_ABI_VERSION 3
 #define T4D_VIEW_FLOATS 40
 #define T4D_GRAD_PAIR_FLOATS 10   /* per (Gaussian,tile) partial-gradient record in the backward scratch */
 
@@ -194,6 +194,30 @@ int t4d_photometric_loss(int32_t n_views, int32_t H, int32_t W, const float *im,
 size_t t4d_masked_l1_scratch_bytes(int32_t n_views);
 int t4d_masked_l1_loss(int32_t n_views, int32_t H, int32_t W, const float *im, const float *gt, const float *mask,
                        const float *view_weight, float *loss, float *dL_dim, void *scratch, size_t scratch_bytes, void *hip_stream);
+
+/* helpers.get_mask (helpers.py:811-823) and the masked target of get_loss's later-frame branch (train.py:320-326; train.py:631,647
+ * hard-code use_mask = True, so this is what every frame after the first optimises against), for the n_views cameras of a
+ * frame in ONE launch - the reference recomputes both in every iteration although they depend on (frame, camera) only.
+ *     hit(pixel)    = OR over the n_labels selected labels of  AND over channels c of  | mask_image[c]*255 - label_colors[k][c] | < 1
+ *     filtered_mask = 1 where hit else 0, on all three channels           (get_mask's return value; NULL = not wanted)
+ *     target        = gt * scale where hit else gt                         (masked_gt, scale = 0.1 at train.py:326; NULL = not wanted)
+ * mask_image, gt, filtered_mask, target: [V,3,H,W] device floats; mask_image is the label image as get_dataset loads it
+ * (train.py:84-92: 8-bit colours / 255).  label_colors: HOST array [n_labels,3] of the selected labels' colours as floats, in the
+ * channel order of the mask image (helpers.py:806 `cmap`: the pascal colormap of 14 labels with its columns swapped to BGR),
+ * n_labels <= T4D_MAX_MASK_LABELS.  Arithmetic is the reference's, rounding for rounding (float32 product, then float32
+ * difference): filtered_mask and target are bit-identical to torch's. */
+#define T4D_MAX_MASK_LABELS 16
+int t4d_label_mask_target(int32_t n_views, int32_t H, int32_t W, const float *mask_image, const float *label_colors /* host */,
+                          int32_t n_labels, const float *gt, float scale, float *filtered_mask, float *target, void *hip_stream);
+
+/* The 'soft_color' term of get_loss_dense (train.py:407; weight 0.02, train.py:541-543): helpers.l1_loss_v2 (helpers.py:119-120)
+ *     *loss = mean over rows of ( sum over width of |x - y| )                                   (UNWEIGHTED, device scalar)
+ *     grad[i] (+)= (weight / rows) * sign(x[i] - y[i])     (sign(0) = 0 as torch's abs; accumulate != 0: added to what grad holds -
+ *                                                           e.g. t4d_rasterize_backward's dL_dcolors; grad NULL = no gradient)
+ * x = dense_rgb_colors, y = dense_init_colors: [rows,width] device floats.  Deterministic (fixed partial-sum order). */
+size_t t4d_soft_color_scratch_bytes(void);
+int t4d_soft_color_loss(int64_t rows, int32_t width, const float *x, const float *y, float weight, float *loss, float *grad,
+                        int32_t accumulate, void *scratch, size_t scratch_bytes, void *hip_stream);
 
 /* Fused optimiser step of Topo4D's loop: torch.optim.Adam (one group per tensor, train.py:272-297) for up to
  * T4D_ADAM_MAX_TENSORS tensors in ONE launch, followed by the per-iteration region freezes of train.py:676-700

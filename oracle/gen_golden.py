@@ -14,6 +14,9 @@ G4  helpers.eval_sh               (helpers.py:865-922) degrees 0..3 on seeded [P
 G7  helpers.compute_vertex_attribute_by_weight_2 (helpers.py:237-253) on a seeded quad mesh
 G8  train.get_loss_dense(..., use_mask=True) (train.py:380-417: helpers.get_mask + the masked L1 of :394-405), called for
     real with `Renderer` bound to a stub that returns a seeded render: loss['im'] and its gradient w.r.t. the render
+G9  train.get_loss(..., use_mask=True) (train.py:300-377) for is_initial_timestep True and False: the branch train.py:631 makes the
+    live one - helpers.get_mask(["inner_mouth"]) (helpers.py:811-823), masked_gt = 0.1 x gt there, camera affine (:310)
+G10 train.get_loss_dense(..., use_mask=False) (train.py:380-417 as :632,:735 call it) incl. 0.02 x soft_color (helpers.py:119-120)
 G6  SELF-GENERATED (not reference-derived): forward outputs + all gradients of oracle/torch_oracle.py (float64)
     on a 64x64 / P=200 scene; pins the oracle against accidental edits.
 The rasterizer itself has no reference-derived golden vectors: its source is absent from /root/reference
@@ -129,6 +132,164 @@ def gen_g8(helpers):
                         masked_elements=np.int64((filtered == 1).sum().item()))
 
 
+class _Recorder:
+    """Wraps a reference function: calls the REAL one and keeps the arguments it was called with."""
+    def __init__(self, fn):
+        self.fn, self.calls = fn, []
+
+    def __call__(self, *a, **k):
+        self.calls.append(a)
+        return self.fn(*a, **k)
+
+
+def _label_image(cmap, labels, H, W, g, perturb=True):
+    """A face-parsing label image as get_dataset loads it (train.py:84-92): uint8 colours / 255.0 in float64, then .float().
+    With `perturb`, a band of pixels sits ONE or TWO grey levels off a label colour in one channel: the `< 1` test of
+    helpers.get_mask (helpers.py:819) then runs within float32 round-off of its threshold."""
+    img = np.stack([cmap[:, c][labels] for c in range(3)], axis=-1).astype(np.int64)          # [H,W,3]
+    if perturb:
+        off = torch.randint(-2, 3, (H, W), generator=g).numpy()
+        ch = torch.randint(0, 3, (H, W), generator=g).numpy()
+        band = np.zeros((H, W), bool)
+        band[::3] = True
+        for c in range(3):
+            sel = band & (ch == c)
+            img[..., c][sel] = np.clip(img[..., c][sel] + off[sel], 0, 255)
+    mask64 = img.astype(np.uint8) / 255.0                                                  # train.py:90
+    return torch.tensor(mask64).float().permute(2, 0, 1)                                   # train.py:92
+
+
+def gen_g9(helpers):
+    """G9: the REAL train.get_loss (train.py:300-377) with use_mask=True - what train.py:631,647 hard-code - for the first frame
+    (is_initial_timestep: the plain photometric branch :318) and for every later frame (:320-327: helpers.get_mask on
+    ["inner_mouth"], masked_gt = gt with the masked elements x 0.1).  `Renderer` is bound to a stub that returns a seeded
+    render (the rasterizer is the un-vendored part); the topology regularisers (out of scope) are bound to
+    stubs that return zero.  Captured: loss['im'], the gradient of the total loss w.r.t. the render, cam_m and cam_c,
+    get_mask's filtered_mask, and the masked_gt the reference handed to l1_loss_v1."""
+    train = import_reference_train()
+    H, W, P, K, n_cams, cid = 48, 40, 12, 3, 4, 2
+    g = torch.Generator().manual_seed(9)
+    cmap = np.asarray(helpers.cmap)
+    target_colors = [torch.tile(torch.tensor(cmap[i]).reshape(3, 1, 1), (1, H, W)) for i in range(14)]     # as train.py:635
+    labels = torch.randint(0, 14, (H // 4, W // 4), generator=g)
+    labels[2:5, 3:7] = 8                                                                   # a solid inner-mouth patch
+    labels = labels.repeat_interleave(4, 0).repeat_interleave(4, 1).numpy()
+    mask = _label_image(cmap, labels, H, W, g)
+    gt = torch.rand(3, H, W, generator=g)
+    radius = torch.randint(0, 5, (P,), generator=g, dtype=torch.int32)
+    zero_pair = lambda *a, **k: (torch.tensor(0.0), None)
+    zero_one = lambda *a, **k: torch.tensor(0.0)
+    losses_list = {k: zero_one for k in ("flat", "flat_lip_bottom", "flat_lip_socket", "flat_eye", "flat_face_bottom")}
+    losses_list.update({k: zero_pair for k in ("flat_lid_top", "flat_lid_bottom", "flat_lip", "flat_mouth")})
+    weights = {'im': 1.0, 'rigid': 3.5, 'rot': 20.0, 'iso': 20.0, 'flat': 2e-4, 'flat_lip_bottom': 2e-4, 'flat_lid_top': 2e-4,
+               'flat_lid_bottom': 1e-2, 'flat_lip': 1e-4, 'flat_mouth': 1e-3, 'flat_eye': 1e4, 'flat_face_bottom': 1e3,
+               'flat_lip_socket': 1e3, 'scale': 10.0, 'scale_max': 10.0}                     # train.py:535-540
+    _zeros = torch.zeros
+    torch.zeros = lambda *a, **k: _zeros(*a, **{kk: v for kk, v in k.items() if kk != "device"})      # external.py:29 says device='cuda'
+    out = {"gt": gt.numpy(), "mask_image": mask.numpy(), "cam_id": np.int64(cid), "radius": radius.numpy()}
+    try:
+        for tag, initial in (("first", True), ("later", False)):
+            im = torch.rand(3, H, W, generator=g).requires_grad_(True)
+
+            class StubRenderer:
+                def __init__(self, raster_settings=None):
+                    pass
+
+                def __call__(self, **kw):
+                    return im, radius, None, None
+            train.Renderer = StubRenderer
+            params = {"means3D": torch.rand(P, 3, generator=g), "rgb_colors": torch.rand(P, 3, generator=g),
+                      "unnorm_rotations": torch.rand(P, 4, generator=g) + 0.1, "logit_opacities": torch.zeros(P, 1),
+                      "log_scales": torch.zeros(P, 3) - 4, "cam_m": (torch.rand(n_cams, 3, generator=g) - 0.5) * 0.2,
+                      "cam_c": (torch.rand(n_cams, 3, generator=g) - 0.5) * 0.1}
+            params = {k: v.requires_grad_(True) for k, v in params.items()}
+            nb = torch.randint(0, P, (P, K), generator=g)
+            variables = {"target_colors_low": target_colors, "max_2D_radius": torch.zeros(P), "init_scale": torch.ones(P),
+                         "neighbor_indices": nb, "prev_inv_rot_fg": torch.rand(P, 4, generator=g), "prev_offset": torch.rand(P, K, 3, generator=g),
+                         "rig_w": torch.rand(P, K, generator=g), "rot_w": torch.rand(P, K, generator=g),
+                         "neighbor_dist": torch.rand(P, K, generator=g), "iso_w": torch.rand(P, K, generator=g),
+                         "cos_init_lid_top": None, "cos_init_lid_bottom": None, "cos_init_lip": None, "cos_init_mouth": None}
+            rec_l1, rec_ssim = _Recorder(helpers.l1_loss_v1), _Recorder(train.calc_ssim)
+            train.l1_loss_v1, train.calc_ssim = rec_l1, rec_ssim
+            curr = {"cam": None, "im": gt, "mask": mask, "id": cid}
+            try:
+                loss, variables, detail = train.get_loss(params, curr, variables, initial, use_mask=True, losses_list=losses_list,
+                                                         losses_weights=weights)
+            finally:
+                train.l1_loss_v1, train.calc_ssim = rec_l1.fn, rec_ssim.fn
+            loss.backward()
+            target_seen = rec_l1.calls[0][1]                                # what the reference compared the render with
+            out[f"{tag}_im"] = im.detach().numpy()
+            out[f"{tag}_cam_m"] = params["cam_m"].detach().numpy()
+            out[f"{tag}_cam_c"] = params["cam_c"].detach().numpy()
+            out[f"{tag}_loss_im"] = np.float32(detail["im"].item())
+            out[f"{tag}_l1"] = np.float32(helpers.l1_loss_v1(rec_l1.calls[0][0], target_seen).item())
+            out[f"{tag}_ssim"] = np.float32(rec_ssim.fn(rec_ssim.calls[0][0], rec_ssim.calls[0][1]).item())
+            out[f"{tag}_grad_im"] = im.grad.numpy()
+            out[f"{tag}_grad_cam_m"] = params["cam_m"].grad.numpy()
+            out[f"{tag}_grad_cam_c"] = params["cam_c"].grad.numpy()
+            out[f"{tag}_target"] = target_seen.detach().numpy()
+            out[f"{tag}_seen"] = variables["seen"].numpy()
+            out[f"{tag}_max_2D_radius"] = variables["max_2D_radius"].numpy()
+    finally:
+        torch.zeros = _zeros
+    filtered = helpers.get_mask(["inner_mouth"], mask, train.cmap_index, target_colors)        # train.py:322-323
+    out["filtered_mask"] = filtered.numpy()
+    # a label image that went through an interpolating rotation / resize (camera.rotate_image, train.py:91): values OFF the
+    # 8-bit grid, many within float32 round-off of the `< 1` threshold - pins the arithmetic (mask * 255, then - colour, in float32)
+    noise = (torch.rand(3, H, W, generator=g) - 0.5) * (2.4 / 255.0)
+    edge = torch.where(torch.rand(3, H, W, generator=g) < 0.5, 1.0, -1.0) * (1.0 + (torch.randint(-3, 4, (3, H, W), generator=g).float() * 2e-7))
+    soft = mask + torch.where(torch.rand(3, H, W, generator=g) < 0.3, edge / 255.0, noise)
+    out["mask_image_soft"] = soft.numpy()
+    out["filtered_mask_soft"] = helpers.get_mask(["inner_mouth"], soft, train.cmap_index, target_colors).numpy()
+    two = helpers.get_mask(["upper_lip", "inner_mouth", "lower_lip"], soft, train.cmap_index, target_colors)
+    out["filtered_mask_soft_3_labels"] = two.numpy()
+    out["label_colors"] = cmap.astype(np.uint8)                                                 # helpers.py:806 (BGR order)
+    out["inner_mouth_index"] = np.int64(train.cmap_index["inner_mouth"])
+    assert np.array_equal(out["first_target"], gt.numpy())                                      # first frame: the plain target
+    assert not np.array_equal(out["later_target"], gt.numpy())
+    np.savez_compressed(os.path.join(OUT, "g9_get_loss_masked.npz"), **out)
+
+
+def gen_g10(helpers):
+    """G10: the REAL train.get_loss_dense (train.py:380-417) as train.py:632,735-737 call it - use_mask False (plain 0.8 L1 + 0.2
+    (1-SSIM) on the render, NO camera affine) plus losses_weights_dense['soft_color'] = 0.02 times helpers.l1_loss_v2
+    (helpers.py:119-120) between dense_rgb_colors and dense_init_colors.  Some colours equal their initial value exactly (the
+    rows train.py:732-734 pin to zero start that way): torch's |x| has gradient 0 there."""
+    train = import_reference_train()
+    H, W, P = 40, 56, 96
+    g = torch.Generator().manual_seed(10)
+    im = torch.rand(3, H, W, generator=g).requires_grad_(True)
+    gt = torch.rand(3, H, W, generator=g)
+    radius = torch.randint(0, 4, (P,), generator=g, dtype=torch.int32)
+
+    class StubRenderer:
+        def __init__(self, raster_settings=None):
+            pass
+
+        def __call__(self, **kw):
+            return im, radius, None, None
+    train.Renderer = StubRenderer
+    init = torch.rand(P, 3, generator=g)
+    rgb = init + (torch.rand(P, 3, generator=g) - 0.5) * 0.2
+    rgb[::5] = init[::5]                                                                     # exact ties: sign(0) = 0
+    rgb[1::7] = 0.0
+    params = {"dense_means3D": torch.rand(P, 3, generator=g), "dense_rgb_colors": rgb.clone().requires_grad_(True),
+              "dense_unnorm_rotations": torch.rand(P, 4, generator=g), "dense_logit_opacities": torch.zeros(P, 1),
+              "dense_log_scales": torch.zeros(P, 3)}
+    variables = {"dense_init_colors": init, "dense_max_2D_radius": torch.zeros(P)}
+    curr = {"cam": None, "im": gt, "mask": None, "id": 0}
+    weights = {"im": 1.0, "soft_color": 0.02}                                                # train.py:541-543
+    loss, variables, detail = train.get_loss_dense(params, curr, variables, 1, 0, None, use_mask=False, losses_list={},
+                                                   losses_weights=weights)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "g10_get_loss_dense.npz"), im=im.detach().numpy(), gt=gt.numpy(), radius=radius.numpy(),
+                        dense_rgb_colors=rgb.numpy(), dense_init_colors=init.numpy(), loss=np.float32(loss.item()),
+                        loss_im=np.float32(detail["im"].item()), loss_soft_color=np.float32(detail["soft_color"].item()),
+                        grad_im=im.grad.numpy(), grad_dense_rgb_colors=params["dense_rgb_colors"].grad.numpy(),
+                        dense_seen=variables["dense_seen"].numpy(), dense_max_2D_radius=variables["dense_max_2D_radius"].numpy())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     helpers, external = import_reference_helpers()
@@ -215,6 +376,8 @@ def main():
 
     # ---- G8 -------------------------------------------------------------------------------------------------
     gen_g8(helpers)
+    gen_g9(helpers)
+    gen_g10(helpers)
 
     # ---- G6 (self-generated) --------------------------------------------------------------------------------
     from oracle import torch_oracle as TO

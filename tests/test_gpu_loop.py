@@ -54,6 +54,7 @@ def test_per_view_loop_fused_vs_torch_pieces():
     import topo4d_amd
     from tests import util
     from scaffold import scene
+    from oracle import loss_oracle
     from topo4d_amd import loop
     from topo4d_amd.optim import FusedAdamPins
     H = W = 64
@@ -71,7 +72,8 @@ def test_per_view_loop_fused_vs_torch_pieces():
         groups = _groups(params, lrs)
         opt = FusedAdamPins(groups, eps=1e-15) if fused else torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         mx = torch.zeros(240, device="cuda")
-        losses = loop.optimise_views(params, dataset, opt, n_iters=7, seed=1, fused_loss=fused, max_2D_radius=mx)
+        losses = loop.optimise_views(params, dataset, opt, n_iters=7, seed=1, max_2D_radius=mx,
+                                     loss_fn=None if fused else loss_oracle.photometric_loss_torch)
         results.append(({k: v.detach().clone() for k, v in params.items()}, torch.stack(losses), mx))
     (pf, lf, mf), (pt, lt, mt) = results
     assert torch.allclose(lf, lt, atol=2e-5), (lf, lt)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import loss_oracle
 from topo4d_amd import loss
 
 pytestmark = pytest.mark.gpu
@@ -41,7 +42,7 @@ def test_matches_torch_restatement_with_camera_affine(shape):
     else:
         dev, dt = "cuda", torch.float32          # full-size case: compare on the GPU against the torch ops
     b = [t.to(dev, dt).requires_grad_(True) for t in (im, cm, cc)]
-    lref = torch.stack([loss.photometric_loss_torch(b[0][v], gt[v].to(dev, dt), b[1][v], b[2][v]) for v in range(V)])
+    lref = torch.stack([loss_oracle.photometric_loss_torch(b[0][v], gt[v].to(dev, dt), b[1][v], b[2][v]) for v in range(V)])
     (lref * wv.to(dev, dt)).sum().backward()
     assert torch.allclose(l.double().cpu(), lref.double().cpu(), atol=3e-6, rtol=0)
     l1_step = 2 * 0.8 * float(wv.max()) / (3 * H * W)        # |d/dx 0.8*mean|x-y|| jumps by this where x' == gt to the last bit
@@ -73,7 +74,7 @@ def test_feeds_the_rasterizer_backward():
         if fused:
             l = loss.photometric_loss(color, gt).sum()
         else:
-            l = sum(loss.photometric_loss_torch(color[v], gt[v]) for v in range(3))
+            l = sum(loss_oracle.photometric_loss_torch(color[v], gt[v]) for v in range(3))
         l.backward()
         res.append((l.item(), {k: v.grad.clone() for k, v in leaves.items()}))
     assert abs(res[0][0] - res[1][0]) < 1e-5
@@ -104,7 +105,7 @@ def test_masked_l1_matches_reference_golden_g8_and_torch():
     (lb[:2] * wv[:2].cuda()).sum().backward()
     for v in range(2):
         ref_in = imb[v].double().requires_grad_(True)
-        ref = loss.masked_l1_loss_torch(ref_in, gtb[v].double(), mask[v].double())
+        ref = loss_oracle.masked_l1_loss_torch(ref_in, gtb[v].double(), mask[v].double())
         (ref * wv[v].double()).backward()
         assert abs(lb[v].item() - ref.item()) < 2e-6 * ref.item()
         np.testing.assert_allclose(a.grad[v].cpu().numpy(), ref_in.grad.numpy(), rtol=1e-5, atol=1e-12)
@@ -169,7 +170,7 @@ def test_random_shapes_against_the_float64_restatement():
         l = loss.photometric_loss(a[0], gt.cuda(), a[1], a[2])
         (l * wv.cuda()).sum().backward()
         b = [t.double().requires_grad_(True) for t in (im, cm, cc)]
-        lref = torch.stack([loss.photometric_loss_torch(b[0][v], gt[v].double(), b[1][v], b[2][v]) for v in range(V)])
+        lref = torch.stack([loss_oracle.photometric_loss_torch(b[0][v], gt[v].double(), b[1][v], b[2][v]) for v in range(V)])
         (lref * wv.double()).sum().backward()
         assert torch.allclose(l.double().cpu(), lref, atol=3e-6, rtol=0), (V, H, W)
         l1_step = 2 * 0.8 * float(wv.max()) / (3 * H * W)

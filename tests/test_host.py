@@ -180,3 +180,36 @@ def test_hand_chained_iteration_has_no_cpu_path_and_checks_its_arguments():
     with pytest.raises(ValueError, match="explicit=True needs"):           # nor can an extra loss term
         loop.optimise_views(p, [data], FusedAdamPins(groups), n_iters=1, extra_loss=lambda a, b: 0.0, explicit=True)
     assert _lib.T4D_FLAG_RAW_PARAMS == 128 and _lib.T4D_ADAM_CLEAR_GRAD == 1
+    # the branches train.py really runs: masked targets, the texture iteration - same rules
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        loss.label_mask_target(torch.zeros(3, 8, 8), [[0, 0, 64]], torch.zeros(3, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        loss.soft_color_loss_raw(torch.zeros(4, 3), torch.zeros(4, 3), 0.02)
+    with pytest.raises(ValueError, match="prepare_masked_targets|label_colors"):
+        loop.target_image(data, use_mask=True, is_initial_timestep=False)
+    assert loop.target_image(data, use_mask=True, is_initial_timestep=True) is data["im"]
+    assert loop.target_image(data, use_mask=False, is_initial_timestep=False) is data["im"]
+    with pytest.raises(ValueError, match="'mask'"):
+        loop.prepare_masked_targets([dict(data)], [[0, 0, 64]])
+    dense, init = scene.make_dense_params({k: v.detach() for k, v in p.items()}, per_vertex=2)
+    dp = {k: torch.nn.Parameter(v) for k, v in dense.items()}
+    dgroups = [{"params": [v], "name": k, "lr": 1e-3} for k, v in dp.items()]
+    with pytest.raises(ValueError, match="explicit=True needs"):
+        loop.optimise_dense_views(dp, {"dense_init_colors": init}, [data], FusedAdamPins(dgroups), n_iters=1, explicit=True)
+    with pytest.raises(ValueError, match="dense_init_colors"):
+        loop.GraphedViews(dp, [data], FusedAdamPins(dgroups, capturable=True), dense=True)
+    opt = FusedAdamPins(dgroups)
+    opt.apply_pins()                                                         # no pins: no launch, no library call
+    assert not hasattr(loss, "photometric_loss_torch") and not hasattr(loss, "ssim_torch")    # the checkers live in oracle/
+
+
+def test_parsing_colormap_is_the_reference_cmap():
+    """scaffold.scene.parsing_colormap_bgr == helpers.py:806 `label_colormap(14)[:, [2, 1, 0]]` (golden G9 holds the real one)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_get_loss_masked.npz"))
+    assert np.array_equal(scene.parsing_colormap_bgr(14), g["label_colors"])
+    assert scene.PARSING_LABELS.index("inner_mouth") == int(g["inner_mouth_index"])
+    m = scene.make_label_image(48, 40, seed=2)
+    assert m.shape == (3, 48, 40) and m.dtype == torch.float32
+    inner = (torch.abs(m * 255 - torch.tensor(g["label_colors"][8]).reshape(3, 1, 1)) < 1).all(0)
+    assert 0 < int(inner.sum()) < 48 * 40 // 4

@@ -10,6 +10,7 @@ import topo4d_amd
 from diff_gaussian_rasterization import GaussianRasterizer as Renderer
 from scaffold import reference_boundary as boundary, scene
 from topo4d_amd import boundary as fused_boundary
+from oracle import loss_oracle
 from topo4d_amd import loss
 
 dev = torch.device("cuda")
@@ -34,7 +35,7 @@ def it_raster(i):
 def it_torch_loss(i):
     rv = boundary.params2rendervar(params)
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
-    l = loss.photometric_loss_torch(im, gts[i % 24]); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    l = loss_oracle.photometric_loss_torch(im, gts[i % 24]); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
 def it_fused_loss(i):
     rv = boundary.params2rendervar(params)
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
@@ -51,7 +52,7 @@ def it_fused_all_act(i):
 def it_torch_all(i):
     rv = boundary.params2rendervar(params)
     im, radius, _, _ = Renderer(raster_settings=cams[i % 24])(**rv)
-    l = loss.photometric_loss_torch(im, gts[i % 24]); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+    l = loss_oracle.photometric_loss_torch(im, gts[i % 24]); l.backward(); opt.step(); opt.zero_grad(set_to_none=True)
     with torch.no_grad():
         for _ in range(8):                                   # train.py:676-700: ~8-16 masked assignments per iteration
             params["means3D"][static_idx] = static_vals

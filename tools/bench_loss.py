@@ -4,6 +4,7 @@ reference (5 conv2d + autograd per view).  Prints one JSON line."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import loss_oracle
 from topo4d_amd import loss
 V, H, W = 24, 512, 512
 g = torch.Generator().manual_seed(0)
@@ -14,7 +15,7 @@ cc = (torch.randn(V, 3, generator=g) * 0.05).cuda().requires_grad_(True)
 def fused():
     l = loss.photometric_loss(im, gt, cm, cc); l.sum().backward()
 def ref():
-    l = sum(loss.photometric_loss_torch(im[v], gt[v], cm[v], cc[v]) for v in range(V)); l.backward()
+    l = sum(loss_oracle.photometric_loss_torch(im[v], gt[v], cm[v], cc[v]) for v in range(V)); l.backward()
 out = {}
 for name, fn, reps in (("fused_hip", fused, 50), ("torch_per_view", ref, 5)):
     for _ in range(3): fn()                          # (allocator, module load, clocks: the first loop of a process is not the steady state)

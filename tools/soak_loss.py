@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Soak run of the fused photometric loss (GPU box): random batches - 1 to 6 views, images from 1 x 1 to 200 x 420, random camera
-affines and view weights - against the float64 torch restatement of the reference (topo4d_amd.loss.photometric_loss_torch, pinned
+affines and view weights - against the float64 torch restatement of the reference (topo4d_amd.loss_oracle.photometric_loss_torch, pinned
 by golden G3), under every kernel a launch can take (T4D_PH_TILE 1 / 32 / 0 = tile kernel in both shapes / strips), and dL/dim
 compared bit for bit between the kernels.     python tools/soak_loss.py [first_seed] [n]"""
 import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import loss_oracle
 from topo4d_amd import loss
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -20,7 +21,7 @@ for seed in range(first, first + n):
     gt = (im + torch.randn(V, 3, H, W, generator=g) * float(rng.uniform(0.01, 0.3))).clamp(0, 1)
     cm, cc = torch.randn(V, 3, generator=g) * 0.1, torch.randn(V, 3, generator=g) * 0.05
     b = [t.double().requires_grad_(True) for t in (im, cm, cc)]
-    lref = torch.stack([loss.photometric_loss_torch(b[0][v], gt[v].double(), b[1][v], b[2][v]) for v in range(V)])
+    lref = torch.stack([loss_oracle.photometric_loss_torch(b[0][v], gt[v].double(), b[1][v], b[2][v]) for v in range(V)])
     lref.sum().backward()
     l1_step = 2 * 0.8 / (3 * H * W)
     outs = []

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # is still no fallback - a path that does not load raises.
 LIB_PATH = os.environ.get("T4D_LIB") or os.path.join(HERE, "csrc", "libtopo4d_raster.so")
 
-T4D_ABI_VERSION = 2
+T4D_ABI_VERSION = 3
 T4D_VIEW_FLOATS = 40
 T4D_GRAD_PAIR_FLOATS = 10
 
@@ -33,7 +33,7 @@ EXPORTS = (
     "t4d_texture_bake", "t4d_texture_render_colors", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
     "t4d_masked_l1_loss", "t4d_masked_l1_scratch_bytes",
     "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
-    "t4d_sum_views",
+    "t4d_sum_views", "t4d_label_mask_target", "t4d_soft_color_loss", "t4d_soft_color_scratch_bytes",
 )
 
 
@@ -69,6 +69,7 @@ class T4DKernelTime(C.Structure):
 
 
 T4D_ADAM_MAX_TENSORS = 12
+T4D_MAX_MASK_LABELS = 16
 
 
 class T4DAdamTensor(C.Structure):
@@ -140,6 +141,14 @@ def load():
     lib.t4d_masked_l1_scratch_bytes.argtypes = [C.c_int32]
     lib.t4d_masked_l1_loss.restype = C.c_int
     lib.t4d_masked_l1_loss.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+    lib.t4d_label_mask_target.restype = C.c_int
+    lib.t4d_label_mask_target.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_void_p, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t4d_soft_color_scratch_bytes.restype = C.c_size_t
+    lib.t4d_soft_color_scratch_bytes.argtypes = []
+    lib.t4d_soft_color_loss.restype = C.c_int
+    lib.t4d_soft_color_loss.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]
     lib.t4d_adam_pin_step.restype = C.c_int
     lib.t4d_adam_pin_step.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.t4d_adam_pin_step_graph.restype = C.c_int

@@ -1,53 +1,23 @@
 """
-Photometric loss on the rendered image — the consumer of the rasterizer output whose gradient is the rasterizer's
-backward input (reference train.py:310,315: per-camera affine, then 0.8*L1 + 0.2*(1-SSIM)).
+Loss assembly around the rasterizer - the consumers of the rasterizer output whose gradient is the rasterizer's backward input
+(reference train.py:300-328 get_loss, :380-417 get_loss_dense) as fused HIP kernels behind the C ABI:
 
-`photometric_loss_torch` restates helpers.py:115-116 (`l1_loss_v1`) and external.py:73-116 (`calc_ssim`: 11x11
-Gaussian window, sigma 1.5, zero padding, c1 = 0.01^2, c2 = 0.03^2, mean over all pixels) with plain torch ops;
-it is pinned by tests/golden/g3_photometric.npz (values captured from the real reference functions).
+    photometric_loss[_raw]   t4d_photometric_loss    per-camera affine (train.py:310) + 0.8*L1 + 0.2*(1-SSIM) (train.py:315; helpers.py:115-116,
+                                                     external.py:73-116), forward and gradient in one launch
+    label_mask_target        t4d_label_mask_target   helpers.get_mask (helpers.py:811-823) + masked_gt (train.py:320-326), once per (frame, camera)
+    soft_color_loss[_raw]    t4d_soft_color_loss     helpers.l1_loss_v2 (helpers.py:119-120): the 'soft_color' term of get_loss_dense (train.py:407)
+    masked_l1_loss           t4d_masked_l1_loss      get_loss_dense's use_mask=True branch (train.py:394-405) - DISABLED in the reference
+                                                     (train.py:632 use_mask_dense = False); kept because the API has it
+
+GPU only: there is no torch fallback in this package.  The plain-torch restatements these kernels are checked against live in
+oracle/loss_oracle.py (test infrastructure), pinned by goldens captured from the real reference (G3, G8, G9, G10).
 """
 from __future__ import annotations
 
-import math
+import ctypes as C
+from typing import Optional, Sequence
 
 import torch
-import torch.nn.functional as F
-
-WINDOW = 11
-SIGMA = 1.5
-C1 = 0.01 ** 2
-C2 = 0.03 ** 2
-
-
-def gaussian_window_1d(dtype=torch.float32, device="cpu") -> torch.Tensor:
-    g = torch.tensor([math.exp(-(x - WINDOW // 2) ** 2 / float(2 * SIGMA ** 2)) for x in range(WINDOW)], dtype=dtype)
-    return (g / g.sum()).to(device)
-
-
-def ssim_torch(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
-    """external.py:85-116 with size_average=True.  img: [C,H,W] or [N,C,H,W]."""
-    squeeze = img1.dim() == 3
-    if squeeze:
-        img1, img2 = img1[None], img2[None]
-    ch = img1.shape[1]
-    w1 = gaussian_window_1d(img1.dtype, img1.device)
-    w2 = (w1[:, None] @ w1[None, :])[None, None].expand(ch, 1, WINDOW, WINDOW).contiguous()
-    pad = WINDOW // 2
-    conv = lambda x: F.conv2d(x, w2, padding=pad, groups=ch)
-    mu1, mu2 = conv(img1), conv(img2)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
-    s1 = conv(img1 * img1) - mu1_sq
-    s2 = conv(img2 * img2) - mu2_sq
-    s12 = conv(img1 * img2) - mu1_mu2
-    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
-    return m.mean()
-
-
-def photometric_loss_torch(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tensor = None, cam_c: torch.Tensor = None):
-    """train.py:310,315: im' = exp(cam_m)[:,None,None]*im + cam_c[:,None,None]; 0.8*mean|im'-gt| + 0.2*(1-SSIM)."""
-    if cam_m is not None:
-        im = torch.exp(cam_m)[:, None, None] * im + cam_c[:, None, None]
-    return 0.8 * torch.abs(im - gt).mean() + 0.2 * (1.0 - ssim_torch(im, gt))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -119,19 +89,8 @@ def photometric_loss(im: torch.Tensor, gt: torch.Tensor, cam_m: torch.Tensor = N
 
 
 # ------------------------------------------------------------------------------------------------------------
-# masked L1 of the dense pass (reference train.py:394-405, get_loss_dense with use_mask=True)
+# masked L1 of the dense pass (reference train.py:394-405, get_loss_dense with use_mask=True: a branch train.py:632 disables)
 # ------------------------------------------------------------------------------------------------------------
-def masked_l1_loss_torch(im: torch.Tensor, gt: torch.Tensor, filtered_mask: torch.Tensor) -> torch.Tensor:
-    """train.py:400-405 restated: masked copies of the render and the target, L1 sum over the number of masked ELEMENTS
-    (the mask image carries the same plane in its three channels; all of them count).  Pinned by tests/golden/g8."""
-    masked_index = filtered_mask == 1
-    masked_im = torch.zeros_like(im)
-    masked_im[masked_index] = im[masked_index]
-    masked_gt = torch.zeros_like(im)
-    masked_gt[masked_index] = gt[masked_index]
-    return (masked_im - masked_gt).abs().sum() / masked_index.sum()
-
-
 class _FusedMaskedL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, gt, mask):
@@ -170,3 +129,100 @@ def masked_l1_loss(im: torch.Tensor, gt: torch.Tensor, filtered_mask: torch.Tens
     if im.dim() == 3:
         return _FusedMaskedL1.apply(im.unsqueeze(0), gt.unsqueeze(0), filtered_mask.unsqueeze(0))[0]
     return _FusedMaskedL1.apply(im, gt, filtered_mask)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# label mask + masked target (helpers.py:811-823, train.py:320-326): once per (frame, camera), not once per iteration
+# ------------------------------------------------------------------------------------------------------------
+MASK_SCALE = 0.1                      # train.py:326
+
+
+def label_mask_target(mask_image: torch.Tensor, label_colors, gt: Optional[torch.Tensor] = None, scale: float = MASK_SCALE,
+                      want_mask: bool = True):
+    """helpers.get_mask for the selected labels and, with `gt`, the masked target of train.py:324-326, for one image [3,H,W] or
+    the V cameras of a frame [V,3,H,W] in ONE launch.  `label_colors`: [n,3] colours of the selected labels (a tensor, array or
+    nested list; the reference's are uint8: helpers.py:806 `cmap[cmap_index[label]]`), in the channel order of the mask image.
+    Returns (filtered_mask or None, target or None), shaped like the inputs; bit-identical to the reference's torch ops."""
+    from . import _lib
+    lib = _lib.load()
+    if not mask_image.is_cuda:
+        raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+    one = mask_image.dim() == 3
+    m = (mask_image[None] if one else mask_image)
+    if m.dim() != 4 or m.shape[1] != 3:
+        raise ValueError("label_mask_target: mask_image must be [3,H,W] or [V,3,H,W]")
+    m = m.float().contiguous()
+    V, _, H, W = m.shape
+    g = None
+    if gt is not None:
+        g = (gt[None] if one else gt).float().contiguous()
+        if g.shape != m.shape or g.device != m.device:
+            raise ValueError("label_mask_target: gt must have the shape and device of mask_image")
+    cols = torch.as_tensor(label_colors).detach().cpu().reshape(-1, 3).to(torch.float32)
+    n = cols.shape[0]
+    if n > _lib.T4D_MAX_MASK_LABELS:
+        raise ValueError(f"label_mask_target: at most {_lib.T4D_MAX_MASK_LABELS} labels")
+    host = (C.c_float * max(3 * n, 1))(*cols.flatten().tolist())
+    filtered = torch.empty_like(m) if want_mask else None
+    target = torch.empty_like(m) if g is not None else None
+    if filtered is None and target is None:
+        raise ValueError("label_mask_target: nothing to compute (no gt and want_mask False)")
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rc = lib.t4d_label_mask_target(V, H, W, p(m), host, n, p(g), float(scale), p(filtered), p(target),
+                                   C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"t4d_label_mask_target failed (code {rc}): {_lib.last_error()}")
+    if one:
+        filtered = None if filtered is None else filtered[0]
+        target = None if target is None else target[0]
+    return filtered, target
+
+
+# ------------------------------------------------------------------------------------------------------------
+# soft colour (helpers.py:119-120 l1_loss_v2; train.py:407 with weight 0.02, train.py:541-543)
+# ------------------------------------------------------------------------------------------------------------
+def soft_color_loss_raw(x: torch.Tensor, y: torch.Tensor, weight: float, grad: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """t4d_soft_color_loss without autograd: returns (UNWEIGHTED l1_loss_v2 as a device scalar, grad).  `grad` [rows,width]
+    receives (accumulate: is increased by) (weight / rows) * sign(x - y); allocated here when None."""
+    from . import _lib
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
+    if grad is None:
+        if accumulate:
+            raise ValueError("soft_color_loss_raw: accumulate needs a gradient tensor to add to")
+        grad = torch.empty_like(x)
+    for name, t in (("x", x), ("y", y), ("grad", grad)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device or t.shape != x.shape or t.dim() != 2:
+            raise ValueError(f"soft_color_loss_raw: {name} must be a contiguous float32 [rows,width] tensor on {x.device}")
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    nbytes = lib.t4d_soft_color_scratch_bytes()
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.t4d_soft_color_loss(x.shape[0], x.shape[1], p(x), p(y), float(weight), p(loss), p(grad), int(bool(accumulate)), p(scratch),
+                                 nbytes, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"t4d_soft_color_loss failed (code {rc}): {_lib.last_error()}")
+    return loss, grad
+
+
+class _FusedSoftColor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        rows = x.shape[0]
+        # weight = rows: the kernel leaves (rows / rows) * sign(x - y) = sign(x - y) exactly; backward scales it by grad / rows like
+        # torch's mean backward.  The divisor is a DEVICE scalar on purpose: torch divides a GPU tensor by a host scalar as a
+        # multiplication by the rounded reciprocal (one bit off); tensor / tensor is a true division - golden G10 bit for bit.
+        loss, sign = soft_color_loss_raw(x.float().contiguous(), y.float().contiguous(), float(rows))
+        ctx.save_for_backward(sign, torch.full((), float(rows), dtype=torch.float32, device=x.device))
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        sign, rows = ctx.saved_tensors
+        return sign * (go / rows), None
+
+
+def soft_color_loss(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """helpers.l1_loss_v2(x, y) (helpers.py:119-120) on the GPU, differentiable w.r.t. x."""
+    return _FusedSoftColor.apply(x, y)

@@ -121,7 +121,34 @@ class FusedAdamPins:
                     p.grad.zero_()
 
     @torch.no_grad()
-    def step(self) -> None:
+    def apply_pins(self, names=None) -> None:
+        """Write the pinned rows of the named tensors (default: every tensor that has pins) WITHOUT an optimiser step: ONE launch
+        of the same kernel with no gradients.  The texture loop pins dense_rgb_colors BEFORE each render and not after the step
+        (train.py:731-734), the geometry loop after it (train.py:676-700: step())."""
+        lib = _lib.load()
+        todo = [g for g in self.param_groups if g["name"] in self._pins and (names is None or g["name"] in names)]
+        if not todo:
+            return
+        arr = (_lib.T4DAdamTensor * len(todo))()
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        for k, g in enumerate(todo):
+            p = g["params"][0]
+            if not p.is_cuda:
+                raise RuntimeError("topo4d_amd has no CPU path: parameters must live on a HIP device")
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise ValueError("parameters must be contiguous float32")
+            rows = p.shape[0] if p.dim() > 0 else 1
+            mask, vals = self._pins[g["name"]]
+            arr[k] = _lib.T4DAdamTensor(ptr(p), None, None, None, ptr(mask), ptr(vals), rows, p.numel() // max(rows, 1), 0.0, 0, 0)
+        dev = todo[0]["params"][0].device
+        rc = lib.t4d_adam_pin_step(arr, len(todo), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"t4d_adam_pin_step failed (code {rc}): {_lib.last_error()}")
+
+    @torch.no_grad()
+    def step(self, pins: bool = True) -> None:
+        """Adam for every tensor that has a gradient, then (pins=True) the pinned rows of every tensor - one launch."""
         lib = _lib.load()
         arr = (_lib.T4DAdamTensor * len(self.param_groups))()
         keep = []
@@ -145,7 +172,7 @@ class FusedAdamPins:
                 st["step"] = st.get("step", 0) + 1           # per parameter, as torch.optim.Adam counts it
                 keep.append(grad)
             st = self.state.get(p, {})
-            mask, vals = self._pins.get(g["name"], (None, None))
+            mask, vals = self._pins.get(g["name"], (None, None)) if pins else (None, None)
             ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
             arr[k] = _lib.T4DAdamTensor(ptr(p), ptr(grad), ptr(st.get("exp_avg")) if grad is not None else None,
                                         ptr(st.get("exp_avg_sq")) if grad is not None else None, ptr(mask), ptr(vals), rows,
