@@ -44,6 +44,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -803,6 +804,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists by design)")
     if os.environ.get("T4D_BENCH_SHARE_GPU") == "1":                   # dry run: several ranks on one GPU (never timed runs)
         local_rank = 0
+    elif torch.cuda.device_count() < max(world, local_rank + 1):
+        # every rank sees the same count and leaves before the rendezvous: no rank is left waiting in init_process_group
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {torch.cuda.device_count()} GPU(s) visible, one per rank needed "
+                         f"(rank {rank}, local rank {local_rank}); nothing was run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # A process group exists whenever a launcher started us (torchrun sets RANK/WORLD_SIZE) - also for ONE rank, so that the

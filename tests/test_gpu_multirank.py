@@ -138,3 +138,97 @@ def test_strong_scaling_rounds_the_job_up_to_whole_steps_per_rank():
                 "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras"], env)
     assert two["config"]["steps_per_rank"] == 4 and two["steps"] == 8 and two["scaling"] == "strong"
     assert two["weak"]["scaling"] == "weak" and two["weak"]["value"] > 0
+
+
+def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
+    """BASELINE config 3's split at its real width: EIGHT ranks (sharing the test GPU, gloo for RCCL), three views per rank and
+    frame, the driver's launch line.  The gathered per-view losses equal the one-rank 24-view launch bit for bit, and so do rank
+    0's gradient checksums (views 0, 8, 16)."""
+    common = ["--steps", "2", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--shard", "views"]
+    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="2")
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "8"] + common, env)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="2"))
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and "view-sharded x8" in eight["config"]["parallelism"]
+    assert eight["config"]["views_per_step_per_gpu"] == 3
+    l8 = np.asarray(eight["gathered_losses_first_steps"], np.float32)        # [step, rank-major 8 x 3]
+    l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [step, 24]
+    np.testing.assert_array_equal(l8.reshape(2, 8, 3).transpose(0, 2, 1).reshape(2, 24), l1)
+    g8 = np.asarray(eight["grad_checksums_first_steps_rank0"], np.float64)
+    g1 = np.asarray(one["grad_checksums_first_steps_rank0"], np.float64)
+    np.testing.assert_array_equal(g8, g1[:, 0::8])
+    assert np.isfinite(l1).all() and np.abs(l1).max() > 0
+
+
+def test_frame_sharded_eight_rank_dry_run_of_the_drivers_default_line():
+    """`bench.py --gpus 8` as the driver launches it (default flags: weak frame sharding as `value`, the fixed 64-frame job as
+    `strong`, the view-sharded split as `view_sharded`), eight ranks sharing the test GPU: every multi-rank object comes out of ONE
+    line and frame f's gathered losses equal the one-rank run's."""
+    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="1")
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--prewarm-s", "0"], env)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["value"] > 0
+    assert eight["config"]["parallelism"] == "frame-sharded x8"
+    assert eight["strong"]["job_frame_steps"] == 64 and eight["strong"]["value"] > 0
+    assert eight["view_sharded"]["views_per_rank"] == 3 and eight["view_sharded"]["value"] > 0
+    one = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras"],
+               dict(os.environ, T4D_BENCH_DUMP_LOSSES="8"))
+    g8 = np.asarray(eight["gathered_losses_first_steps"], np.float32)        # [1 step, 8 ranks x 24]: frames 0..7
+    g1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [8 steps, 24]
+    assert g8.shape == (1, 192) and g1.shape == (8, 24)
+    np.testing.assert_array_equal(g8.reshape(8, 24), g1)
+
+
+def test_eight_gpu_command_line_on_a_one_gpu_box_leaves_cleanly():
+    """The driver's N = 8 command on a box that shows fewer than eight GPUs: every rank prints one line and exits before the
+    rendezvous - no hang, no traceback, nothing run."""
+    if __import__("torch").cuda.device_count() >= 8:
+        pytest.skip("eight GPUs visible: the command would run")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("T4D_BENCH_SHARE_GPU", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) visible, one per rank needed" in r.stderr and "nothing was run" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _unequal_shard_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from scaffold import scene
+    from tests import util
+    from topo4d_amd import ViewBatch, dist as t4d_dist, loss, pack_views
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H = W = 64
+        rv, cams = util.make_scene(12, 20, H, W, 24, opacity="B", seed=2)
+        dev = torch.device("cuda")
+        gt = torch.rand(24, 3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+
+        def losses_of(units):
+            dcams = util.to_device([cams[u] for u in units], dev)
+            b = ViewBatch(pack_views(dcams, dev), H, W)
+            im, _, _, _ = b.forward(rv["means3D"].to(dev), rv["opacities"].to(dev), rv["scales"].to(dev), rv["rotations"].to(dev),
+                                    rv["colors_precomp"].to(dev))
+            return loss.photometric_loss_raw(im, gt[units].contiguous())[0]
+        mine = t4d_dist.shard_units(24, rank, world)                       # 24 views over 5 ranks: 5, 5, 5, 5, 4
+        got = t4d_dist.gather_losses(losses_of(mine), n_units=24)
+        if rank == 0:
+            np.save(out_path, np.stack([got.cpu().numpy(), losses_of(list(range(24))).cpu().numpy()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unequal_view_shards_gather_in_unit_order_on_the_gpu_path(tmp_path):
+    """24 views over FIVE ranks (5, 5, 5, 5, 4 views): each rank renders its views and computes their losses on the GPU,
+    dist.gather_losses(n_units=24) pads, gathers and restores unit order; equal to the one-launch losses bit for bit."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "unequal.npy")
+    mp.spawn(_unequal_shard_worker, args=(5, _free_port(), out), nprocs=5, join=True)
+    got, want = np.load(out)
+    assert got.shape == (24,) and np.isfinite(want).all() and want.max() > 0
+    np.testing.assert_array_equal(got, want)

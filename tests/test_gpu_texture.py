@@ -133,6 +133,19 @@ def test_sharded_bake_two_ranks_equals_single_bake(tmp_path):
     np.testing.assert_array_equal(a, b)
 
 
+def test_sharded_bake_eight_ranks_equals_single_bake(tmp_path):
+    """BASELINE config 5's 1 -> 8 shard at its real width: eight ranks (sharing the test GPU, gloo for RCCL), 250 rows in bands of
+    32 / 31, byte-identical to the single bake."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sharded8.npy")
+    mp.spawn(_sharded_bake_worker, args=(8, port, out), nprocs=8, join=True)
+    a, b = np.load(out), np.load(out + ".single.npy")
+    assert a.shape == (250, 250, 3) and a.any()
+    np.testing.assert_array_equal(a, b)
+
+
 def test_sharded_bake_through_rccl_with_one_rank(tmp_path):
     """The RCCL ("nccl") branch of the band gather executed for real: a process group of ONE rank on the test box's one GPU -
     init with device_id, all_gather_into_tensor of the band on the device, destroy - before an 8-GPU node ever sees it."""
