@@ -835,7 +835,10 @@ def main():
     if by_views:
         # one frame is in flight: the frames of the loop this split serves are sequential (train.py:646)
         args.scaling, args.in_flight = "strong", 1
-        wl = Workload(args.config, args.opacity, dev, rank, world, 1, gather=dist is not None, view_shard=(rank, world),
+        shard = (rank, world)
+        if world == 1 and os.environ.get("T4D_BENCH_VIEW_SHARD"):     # tests: ONE process renders rank r's shard of an N-way split ("r/N")
+            shard = tuple(int(x) for x in os.environ["T4D_BENCH_VIEW_SHARD"].split("/"))
+        wl = Workload(args.config, args.opacity, dev, rank, world, 1, gather=dist is not None, view_shard=shard,
                       allreduce_grads=args.allreduce_grads)
     else:
         wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from tests import util
-from tests.test_gpu_parity import (check_grads, check_grads_modulo_flips, check_n_contrib, check_outputs,
+from tests.test_gpu_parity import (check_grads, check_grads_modulo_flips, check_n_contrib, check_outputs, check_view_modulo_flips,
                                     flipped_pixels)
 
 pytestmark = pytest.mark.gpu
@@ -109,20 +109,17 @@ def test_c4_full_size_sh3(opacity):
         if g1[k] is not None:
             np.testing.assert_array_equal(g1[k], g[k][sub])
             np.testing.assert_array_equal(g2[k], 2 * g1[k])
-    # two sampled views against the C oracle
-    for v in (5, 18):
-        r, gref = util.c_oracle_render(cams[v], rv, dc[v])
-        np.testing.assert_array_equal(radii[v], r.radii)
-        assert int(st["view_total"][v]) == r.num_rendered
-        os_ = r.state()
-        np.testing.assert_array_equal(st["tile_count"][v], os_["ranges"][:, 1] - os_["ranges"][:, 0])
-        # 4.2 M pixels per view: a T < 1e-4 / alpha >= 1/255 decision within an ulp of its threshold can fall the other way
-        # (device exp vs glibc expf) on a handful of them - at most 4 per view here, never a systematic difference
-        check_n_contrib(st["n_contrib"][v], os_["n_contrib"], max_flips=4)
-        check_outputs(out, r.color, r.depth, r.alpha, v, max_flips=4)
-        flips = flipped_pixels(out, v, r, st["n_contrib"][v])
-        check_grads_modulo_flips(g, gref, v, flips, st["xy"][v], radii[v],
-                                 keys=("means3D", "means2D", "opacities", "scales", "rotations", "shs"))
+    # SIX of the 24 views against the C oracle (the oracle calls release the GIL: six threads).  4.2 M pixels per view: a
+    # T < 1e-4 / alpha >= 1/255 decision within an ulp of its threshold can fall the other way (device exp vs glibc expf) on a
+    # handful of them - at most 8 per view here (scenario B blends ten times more splats per pixel than A: 5 on one view, 0-2 on
+    # the others), never a systematic difference
+    six = (1, 5, 9, 14, 18, 22)
+    total = 0
+    for v, (r, gref) in zip(six, util.c_oracle_render_many([cams[v] for v in six], rv, [dc[v] for v in six])):
+        total += check_view_modulo_flips(out, g, v, r, gref, st, max_flips=8,
+                                         keys=("means3D", "means2D", "opacities", "scales", "rotations", "shs"))
+    assert total <= 16, f"{total} threshold pixels in 6 views"
+    print(f"config 4-{opacity}, 6 views against the C oracle: {total} threshold pixels")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -147,14 +144,12 @@ def test_c2_full_size_scenario_b():
     lhs = (gc["colors_precomp"].astype(np.float64) * rgb[None]).sum(axis=(1, 2))
     rhs = (dc.numpy().astype(np.float64) * out["color"]).sum(axis=(1, 2, 3))
     np.testing.assert_allclose(lhs, rhs, rtol=2e-4, atol=1e-9)
-    for v in (3, 20):
-        r, gref = util.c_oracle_render(cams[v], rv, dc[v], dd[v], da[v])
-        np.testing.assert_array_equal(out["radii"][v], r.radii)
-        os_ = r.state()
-        np.testing.assert_array_equal(st["tile_count"][v], os_["ranges"][:, 1] - os_["ranges"][:, 0])
-        check_n_contrib(st["n_contrib"][v], os_["n_contrib"])
-        check_outputs(out, r.color, r.depth, r.alpha, v)
-        check_grads(g, gref, v)
+    # ALL 24 views against the C oracle (threads: the oracle calls release the GIL); threshold pixels as in the scenario-A test
+    total = 0
+    for v, (r, gref) in enumerate(util.c_oracle_render_many(cams, rv, dc, dd, da)):
+        total += check_view_modulo_flips(out, g, v, r, gref, st, max_flips=2)
+    assert total <= 8, f"{total} threshold pixels in 24 views"
+    print(f"config 2-B, 24 views against the C oracle: {total} threshold pixels")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -326,14 +321,17 @@ BUILDS = (("throughput", {"T4D_LATENCY_TILES": "0", "T4D_NO_SEGMENTS": "1"}),   
 
 
 def test_randomised_soak_all_builds(monkeypatch):
-    """Time-boxed soak inside the suite: at least 50 further seeds under EVERY build of the render kernels (more while the box
-    has time left).  Round 2's soak of 400 runs (tools/soak_parity.py) had one scene miss the plain gradient tolerance because
+    """A FIXED slice of tools/soak_parity.py inside the driver-run suite: seeds 12..211 - 200 randomised
+    scenes against the C oracle with the flip-aware check - each under one of the three builds of the render kernels (seed mod 3),
+    the first 20 under all three: 240 runs.  Round 2's soak of 400 runs had one scene miss the plain gradient tolerance because
     of ONE threshold pixel; with the flip-aware check every run must be green."""
     import time
     t0 = time.time()
-    done = flips = 0
-    for trial in range(12, 412):
-        for name, env in BUILDS:
+    runs = flips = 0
+    for trial in range(12, 212):
+        for b, (name, env) in enumerate(BUILDS):
+            if trial >= 32 and trial % 3 != b:
+                continue
             monkeypatch.delenv("T4D_NO_SEGMENTS", raising=False)
             for k, val in env.items():
                 monkeypatch.setenv(k, val)
@@ -341,11 +339,9 @@ def test_randomised_soak_all_builds(monkeypatch):
                 flips += _randomised_trial(trial)
             except AssertionError as e:
                 raise AssertionError(f"trial {trial} ({name}): {e}") from e
-        done += 1
-        if done >= 50 and time.time() - t0 > 150.0:
-            break
-    assert done >= 50
-    print(f"soak: {done} seeds x {len(BUILDS)} builds, {flips} threshold pixels in total, {time.time() - t0:.0f} s")
+            runs += 1
+    assert runs == 240
+    print(f"soak: 200 seeds, {runs} runs over {len(BUILDS)} builds, {flips} threshold pixels in total, {time.time() - t0:.0f} s")
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -201,16 +201,17 @@ def test_c2_full_size_gradient_identities(c2):
         assert np.isfinite(g[k]).all()
 
 
-def test_c2_full_size_sampled_views_against_c_oracle(c2):
-    for v in (0, 13):
-        r, gref = util.c_oracle_render(c2["cams"][v], c2["rv"], c2["dc"][v], c2["dd"][v], c2["da"][v])
-        np.testing.assert_array_equal(c2["out"]["radii"][v], r.radii)
-        assert int(c2["st"]["view_total"][v]) == r.num_rendered
-        os_ = r.state()
-        np.testing.assert_array_equal(c2["st"]["tile_count"][v], os_["ranges"][:, 1] - os_["ranges"][:, 0])
-        check_n_contrib(c2["st"]["n_contrib"][v], os_["n_contrib"])
-        check_outputs(c2["out"], r.color, r.depth, r.alpha, v)
-        check_grads(c2["g"], gref, v)
+def test_c2_full_size_all_views_against_c_oracle(c2):
+    """BASELINE config 2 at full size, scenario A: EVERY one of the 24 views - radii, pair counts, per-tile counts, last
+    contributors, colour / depth / alpha and all gradients - against the C oracle (threads: the oracle calls release the GIL).
+    6.3 M pixels: a view may hold up to two threshold pixels, the launch at most eight; every Gaussian without one
+    in reach meets the plain tolerance."""
+    from tests.test_gpu_parity import check_view_modulo_flips
+    total = 0
+    for v, (r, gref) in enumerate(util.c_oracle_render_many(c2["cams"], c2["rv"], c2["dc"], c2["dd"], c2["da"])):
+        total += check_view_modulo_flips(c2["out"], c2["g"], v, r, gref, c2["st"], max_flips=2)
+    assert total <= 8, f"{total} threshold pixels in 24 views"
+    print(f"config 2-A, 24 views against the C oracle: {total} threshold pixels")
 
 
 @pytest.mark.parametrize("views", [(0, 8, 16), (13,)])
@@ -339,6 +340,33 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
     finally:
         topo4d_amd.set_sync_mode("checked")
         rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
+
+
+def test_auto_mode_status_ring_never_hands_out_a_slot_that_is_still_owned():
+    """statuses harvested out of order (a backward waiting for ITS forward) lower the in-flight count while an older
+    slot of the ring is still owned; claim() must not hand that slot out again before its owner is settled."""
+    from topo4d_amd import rasterizer
+    rasterizer._PENDING.clear()
+    try:
+        track = rasterizer._AutoTrack(key=(torch.cuda.current_device(), 1, 1, 1))
+        landed = lambda e, need=7: (track.host.__setitem__((e.slot, 0), need << 32), track.host.__setitem__((e.slot, 1), 0))
+        e0 = track.claim(100)                               # an old forward whose status never lands (stands for: still in flight)
+        later = []
+        for _ in range(track.RING - 1):                     # slots 1..7, each harvested out of order by "its own backward"
+            e = track.claim(100)
+            landed(e)
+            rasterizer.poll_truncation(wait_for=e)
+            assert e.done and not e0.done
+            later.append(e)
+        assert track.count == 1 and track.head == e0.slot   # the count says "one in flight", the head points at e0's slot
+        e8 = track.claim(100)                               # must settle e0 first (poll, then synchronise and forget it)
+        assert e0.done and e8.slot == e0.slot and track.live[e8.slot] is e8
+        assert [e for e in rasterizer._PENDING] == [e8]
+        landed(e8, need=9)
+        rasterizer.poll_truncation(wait_for=e8)
+        assert track.need == 9 and track.count == 0 and not rasterizer._PENDING
+    finally:
+        rasterizer._PENDING.clear()
 
 
 def test_view_summed_gradients_in_one_launch():

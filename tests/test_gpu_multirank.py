@@ -142,8 +142,10 @@ def test_strong_scaling_rounds_the_job_up_to_whole_steps_per_rank():
 
 def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
     """BASELINE config 3's split at its real width: EIGHT ranks (sharing the test GPU, gloo for RCCL), three views per rank and
-    frame, the driver's launch line.  The gathered per-view losses equal the one-rank 24-view launch bit for bit, and so do rank
-    0's gradient checksums (views 0, 8, 16)."""
+    frame, the driver's launch line.  A three-view launch runs the depth-SEGMENTED backward, whose replay starts
+    from the forward's snapshots: its sums - and the per-view scalar <colour, dL/dcolour> the ranks gather, a by-product of that
+    replay - agree with the whole-tile replay of the 24-view launch to summation-order rounding, not bit for bit (the two-rank
+    test, 12 views per launch, is the bit-for-bit one).  What IS exact: every view lands in its slot of the gathered vector."""
     common = ["--steps", "2", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--shard", "views"]
     env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="2")
     eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
@@ -153,11 +155,17 @@ def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
     assert eight["config"]["views_per_step_per_gpu"] == 3
     l8 = np.asarray(eight["gathered_losses_first_steps"], np.float32)        # [step, rank-major 8 x 3]
     l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [step, 24]
-    np.testing.assert_array_equal(l8.reshape(2, 8, 3).transpose(0, 2, 1).reshape(2, 24), l1)
+    unit_order = l8.reshape(2, 8, 3).transpose(0, 2, 1).reshape(2, 24)
+    np.testing.assert_allclose(unit_order, l1, rtol=5e-6, atol=1e-10)
+    # the 24 scalars of a frame are all different: a view in the wrong slot would be off by orders of magnitude more
+    assert np.abs(l1[0][:, None] - l1[0][None, :])[~np.eye(24, dtype=bool)].min() > 100 * np.abs(unit_order - l1).max()
     g8 = np.asarray(eight["grad_checksums_first_steps_rank0"], np.float64)
     g1 = np.asarray(one["grad_checksums_first_steps_rank0"], np.float64)
-    np.testing.assert_array_equal(g8, g1[:, 0::8])
+    np.testing.assert_allclose(g8, g1[:, 0::8], rtol=1e-5)
     assert np.isfinite(l1).all() and np.abs(l1).max() > 0
+    # the same three views per launch in ONE process (the segmented build on both sides): bit for bit
+    one3 = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="2", T4D_BENCH_VIEW_SHARD="0/8"))
+    np.testing.assert_array_equal(np.asarray(one3["gathered_losses_first_steps"], np.float32), l8.reshape(2, 8, 3)[:, 0, :])
 
 
 def test_frame_sharded_eight_rank_dry_run_of_the_drivers_default_line():

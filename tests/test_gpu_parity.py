@@ -85,6 +85,25 @@ def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_K
                 f"grad {k}[view {v}], Gaussian {i}: err {err[i]:.3e} vs scale {scale:.3e} is more than one pixel's share"
 
 
+def check_view_modulo_flips(hip, hip_g, v, r, ref_g, st, max_flips, keys=util.GRAD_KEYS, truth=None):
+    """One view of a full-size launch against its C-oracle render `r`: integer state exact; at most `max_flips` THRESHOLD pixels
+    (a discrete decision within round-off of its threshold, `v_exp_f32` vs glibc's expf: DESIGN section 2 - about one scene in forty
+    has one), everything else within the plain tolerances.  Returns the number of threshold pixels."""
+    np.testing.assert_array_equal(hip["radii"][v], r.radii)
+    assert int(st["view_total"][v]) == r.num_rendered
+    os_ = r.state()
+    np.testing.assert_array_equal(st["tile_count"][v], os_["ranges"][:, 1] - os_["ranges"][:, 0])
+    flips = flipped_pixels(hip, v, r, st["n_contrib"][v])
+    assert len(flips) <= max_flips, f"view {v}: {len(flips)} pixels took a discrete decision the other way"
+    check_n_contrib(st["n_contrib"][v], os_["n_contrib"], max_flips=len(flips))
+    check_outputs(hip, r.color, r.depth, r.alpha, v, max_flips=len(flips))
+    if len(flips) == 0:
+        check_grads(hip_g, ref_g, v, keys=keys)
+    else:
+        check_grads_modulo_flips(hip_g, ref_g, v, flips, st["xy"][v], hip["radii"][v], keys=keys, truth=truth)
+    return len(flips)
+
+
 def check_n_contrib(mine, ref, max_flips=0):
     diff = int((np.asarray(mine) != np.asarray(ref)).sum())
     assert diff <= max_flips, f"n_contrib differs on {diff} pixels"

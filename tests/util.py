@@ -65,6 +65,19 @@ def c_oracle_render(cam, rv, dc=None, dd=None, da=None):
     return r, g
 
 
+def c_oracle_render_many(cams, rv, dcs=None, dds=None, das=None, threads=None):
+    """c_oracle_render for several views at once: the C oracle is called through ctypes, which releases the GIL, so a thread per
+    view uses the host's cores.  Yields (OracleRender, grads) in view order."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(cams)
+    pick = lambda xs, i: None if xs is None else xs[i]
+    with ThreadPoolExecutor(max_workers=threads or min(n, max(1, (os.cpu_count() or 2) // 2))) as ex:
+        futs = [ex.submit(c_oracle_render, cams[i], rv, pick(dcs, i), pick(dds, i), pick(das, i)) for i in range(n)]
+        for f in futs:
+            yield f.result()
+
+
 def torch_oracle_render(cam, rv, dc=None, dd=None, da=None, dtype=torch.float64):
     view = TO.View(*cam)
     outs, grads = TO.rasterize_with_grads(view, rv["means3D"], rv["opacities"], rv.get("scales"), rv.get("rotations"),

@@ -619,6 +619,26 @@ T4D_EXPORT int t4d_debug_state_layout(const T4DProblem *prob, int has_sh, uint64
     return T4D_OK;
 }
 
+// how many workgroups of k_front_small the current device holds at once (occupancy x compute units; cached per device)
+static unsigned front_small_resident_blocks()
+{
+    static int cached_dev = -1;
+    static unsigned cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev != cached_dev) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_front_small, kBlock, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1) {
+            (void)hipGetLastError();
+            per_cu = 0; cus = 0;                         // unknown: never take the barrier kernel
+        }
+        cached = (unsigned)per_cu * (unsigned)cus;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO *io, T4DStatus *status, void *hip_stream)
 {
     int rc = check_problem(prob);
@@ -664,7 +684,10 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // one view of at most 1,024 tiles (Topo4D's own call shape): scan and scatter are ONE launch (k_scan_scatter_small), and with
     // at most 128 workgroups of Gaussians (all resident at once) preprocess joins them behind a grid-wide barrier (k_front_small)
     const bool small_view = p.n_views == 1 && kp.T <= kSmallTiles && getenv("T4D_NO_SMALL_VIEW") == nullptr;
-    const bool front = small_view && gaussian_grid(p.P, 1) + 1u <= 128u && getenv("T4D_NO_FRONT_FUSION") == nullptr;
+    // (the grid barrier is only safe when every workgroup of the launch is resident at once: checked against what the DEVICE can
+    // hold - a CU mask or a compute partition of 32 CUs shows up in device_cus() - not assumed from the workgroup count)
+    const bool front = small_view && gaussian_grid(p.P, 1) + 1u <= 128u && gaussian_grid(p.P, 1) + 1u <= front_small_resident_blocks() &&
+                       getenv("T4D_NO_FRONT_FUSION") == nullptr;
     { ProfScope ps_(stream, K_PREPROCESS);
     if (front) hipLaunchKernelGGL(k_front_small, dim3(gaussian_grid(p.P, 1) + 1), dim3(kBlock), 0, stream, kp);
     else hipLaunchKernelGGL(k_preprocess, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);

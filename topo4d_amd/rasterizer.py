@@ -78,7 +78,7 @@ class _AutoTrack:
     value before its forward is enqueued; the forward's asynchronous device-to-host copy overwrites it, so "has it landed?"
     is two host loads - no event, no stream object on the per-iteration path."""
     RING = 8
-    __slots__ = ("pinned", "host", "args", "head", "count", "need", "key")
+    __slots__ = ("pinned", "host", "args", "head", "count", "need", "key", "live")
 
     def __init__(self, key=None):
         self.key = key                                  # (device_index, P, H, W) whose capacity this track feeds
@@ -89,23 +89,30 @@ class _AutoTrack:
         self.head = 0                                   # next slot to hand out
         self.count = 0                                  # slots in flight
         self.need = 0
+        self.live = [None] * self.RING                  # per slot: the _Pending that owns it (statuses may be harvested out of order)
 
     def claim(self, cap: int) -> "_Pending":
         """Reserves the next slot for a forward that is about to be enqueued; `self.args[entry.slot]` is the status pointer to
         pass to it."""
-        if self.count == self.RING:                     # the host is RING forwards of this camera set ahead of the GPU
+        # the ring is full, or - after an out-of-order harvest (a backward waiting for ITS forward on another stream) - the slot
+        # at the head still belongs to an older forward whose status the GPU has yet to write
+        owner = self.live[self.head]
+        if self.count == self.RING or (owner is not None and not owner.done):
             poll_truncation()
-            if self.count == self.RING:
-                torch.cuda.synchronize()
-                # everything that was enqueued has landed by now: harvest it (a truncated pass among them raises here); a slot
-                # that still reads "not yet" belongs to a forward that was never enqueued and can only be forgotten
-                poll_truncation(_after_sync=True)
+            owner = self.live[self.head]
+            if self.count == self.RING or (owner is not None and not owner.done):
+                dev_index = self.key[0] if self.key is not None else None
+                torch.cuda.synchronize(dev_index)
+                # everything that was enqueued on that device has landed by now: harvest it (a truncated pass among them raises
+                # here); a slot that still reads "not yet" belongs to a forward that was never enqueued and can only be forgotten
+                poll_truncation(_after_sync=True, _synced_device=dev_index)
         i = self.head
         self.host[i, 0] = -1
         self.host[i, 1] = -1
         self.head = (i + 1) % self.RING
         self.count += 1
         entry = _Pending(self, i, cap)
+        self.live[i] = entry
         _PENDING.append(entry)
         return entry
 
@@ -147,7 +154,7 @@ def _truncation_error(truncated) -> RuntimeError:
         "enlarged: re-run that iteration, or use set_sync_mode('checked') for scenes that change abruptly.")
 
 
-def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = False) -> None:
+def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = False, _synced_device=None) -> None:
     """"auto" sync mode: look at every binning status that has landed since the last look - of ALL camera sets, not only
     the one being rendered - grow the arenas they ask for, and raise RuntimeError if any of those forwards was truncated.
     Every auto-mode forward calls this first, and every auto-mode BACKWARD calls it for its own forward (`wait_for`, below) before
@@ -162,16 +169,29 @@ def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = F
         t0 = time.perf_counter()
         while not wait_for.landed():
             if time.perf_counter() - t0 > 1.0:
-                torch.cuda.synchronize()
+                # the device the forward ran on, not whichever is current
+                key = wait_for.track.key
+                torch.cuda.synchronize(key[0] if key is not None else None)
+                if not wait_for.landed():
+                    # (a forward on a capturing stream, or one that never ran): no gradient of a render whose status is unknown
+                    raise RuntimeError("topo4d_amd (sync_mode='auto'): the binning status of this backward's forward has not arrived "
+                                       "after a device synchronisation; refusing to return gradients of a render that may be truncated")
                 break
     while _PENDING:
         entry = _PENDING[0]
         if not entry.landed():
-            if _after_sync:                             # can never land: its forward was not enqueued
-                _PENDING.popleft()
-                entry.done = True
-                entry.track.count -= 1
-                continue
+            if _after_sync:
+                key = entry.track.key
+                if _synced_device is None or key is None or key[0] == _synced_device:
+                    _PENDING.popleft()                  # can never land: its forward was not enqueued
+                    entry.done = True
+                    entry.track.count -= 1
+                    continue
+                # an entry of ANOTHER device: it may still be in flight - leave it, look past it
+                later = [e for e in list(_PENDING)[1:] if e.landed()]
+                for e in later:
+                    _PENDING.remove(e)
+                    truncated = _harvest(e) or truncated
             break
         _PENDING.popleft()
         truncated = _harvest(entry) or truncated
