@@ -68,10 +68,10 @@ def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypa
     rv, cams = util.make_scene(20, 32, H, W, 3, opacity="B", seed=4)
     dc, _, _ = scene.output_cotangents(3, H, W, seed=5)
     ref, gref, _ = util.hip_render(cams, rv, dc)
-    key = (torch.device("cuda").index or 0, 640, H, W)
+    dev_index = torch.device("cuda").index or 0
     # (a) checked: start far too small -> T4D_ERR_PAIR_OVERFLOW -> retried with a larger arena, same results
     monkeypatch.setattr(rasterizer, "_initial_capacity", lambda P: 256)
-    rasterizer._CAPACITY.clear()
+    rasterizer._forget_scenes()
     out, g, batch = util.hip_render(cams, rv, dc)
     assert batch.prob.pair_capacity > 256 and batch.last_status.overflow == 0
     for k in ref:
@@ -80,8 +80,8 @@ def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypa
         if gref[k] is not None:
             np.testing.assert_array_equal(g[k], gref[k])
     # (b) lazy with a wrong learned capacity: lists are truncated, nothing is written out of bounds, status says so
-    rasterizer._CAPACITY[(0, 640, H, W)] = 512
-    rasterizer._CAPACITY[key] = 512
+    rasterizer._scene(0, 640, H, W).capacity = 512
+    rasterizer._scene(dev_index, 640, H, W).capacity = 512
     topo4d_amd.set_sync_mode("lazy")
     try:
         out2, g2, batch2 = util.hip_render(cams, rv, dc)
@@ -97,7 +97,7 @@ def test_checked_mode_grows_the_pair_arena_and_lazy_mode_is_memory_safe(monkeypa
         assert not dot.any()                            # ... and so is the per-view <outputs, cotangents>
     finally:
         topo4d_amd.set_sync_mode("checked")
-        rasterizer._CAPACITY.clear()
+        rasterizer._forget_scenes()
 
 
 def test_view_dot_and_mark_visible():
@@ -297,7 +297,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
     call = lambda r, sc=1.0: r(d["means3D"], None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * sc,
                                rotations=d["rotations"])
     ref = [[t.clone() for t in call(r)] for r in R]
-    rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
+    rasterizer._forget_scenes()
     topo4d_amd.set_sync_mode("auto")
     try:
         for it in range(4):                                   # first call per camera is checked, the rest are not
@@ -305,7 +305,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
                 out = call(r)
                 for a, b in zip(out, ref[k]):
                     assert torch.equal(a, b)
-        tracks = list(rasterizer._AUTO.values())
+        tracks = [t for sc in rasterizer._SCENES.values() for t in sc.tracks.values()]
         assert len(tracks) == 2 and all(t.need > 0 for t in tracks)
         # a slowly growing scene (scales +8 % per iteration): capacity follows, nothing is ever truncated
         sc = 1.0
@@ -324,7 +324,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
             assert torch.equal(a, b)
         # an abrupt jump (scales x6 from one call to the next) overflows once: the truncated render's OWN backward raises, before
         # any gradient exists and before an optimiser could step (it used to return zero gradients and raise one call later)
-        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
+        rasterizer._forget_scenes()
         call(R[0]); call(R[0])
         leaf = d["means3D"].clone().requires_grad_(True)
         out_t = R[0](leaf, None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * 6.0, rotations=d["rotations"])
@@ -339,7 +339,7 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
             assert torch.equal(a, b)
     finally:
         topo4d_amd.set_sync_mode("checked")
-        rasterizer._CAPACITY.clear(); rasterizer._AUTO.clear(); rasterizer._PENDING.clear()
+        rasterizer._forget_scenes()
 
 
 def test_auto_mode_status_ring_never_hands_out_a_slot_that_is_still_owned():
@@ -348,7 +348,7 @@ def test_auto_mode_status_ring_never_hands_out_a_slot_that_is_still_owned():
     from topo4d_amd import rasterizer
     rasterizer._PENDING.clear()
     try:
-        track = rasterizer._AutoTrack(key=(torch.cuda.current_device(), 1, 1, 1))
+        track = rasterizer._AutoTrack(rasterizer._Scene((torch.cuda.current_device(), 1, 1, 1)))
         landed = lambda e, need=7: (track.host.__setitem__((e.slot, 0), need << 32), track.host.__setitem__((e.slot, 1), 0))
         e0 = track.claim(100)                               # an old forward whose status never lands (stands for: still in flight)
         later = []

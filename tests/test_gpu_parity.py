@@ -255,10 +255,10 @@ def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch)
     from scaffold import scene
     cams = scene.camera_rig(H, W, n_views=1)
     dc, dd, da = scene.output_cotangents(V, H, W, seed=4, depth_alpha=True)
-    rasterizer._LONGEST_BIN.clear()
+    rasterizer._forget_scenes()
     if hint == "no-long-bins":
-        monkeypatch.setitem(rasterizer._LONGEST_BIN, (0, P, H, W), 100)
-        monkeypatch.setitem(rasterizer._CAPACITY, (0, P, H, W), 16 * P + 1024)     # known scene size: no checked retry
+        rasterizer._scene(0, P, H, W).longest_bin = 100
+        rasterizer._scene(0, P, H, W).capacity = 16 * P + 1024                     # known scene size: no checked retry
     hip, hg, batch = util.hip_render(cams, rv, dc, dd, da)
     if hint == "no-long-bins":
         assert batch.prob.flags & 16
@@ -279,7 +279,7 @@ def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch)
     assert len(flips) <= 3
     check_outputs(hip, r.color, r.depth, r.alpha, 0, max_flips=len(flips))
     check_grads_modulo_flips(hg, gref, 0, flips, st["xy"][0], hip["radii"][0])
-    rasterizer._LONGEST_BIN.clear()
+    rasterizer._forget_scenes()
 
 
 def test_bins_of_exactly_the_lds_sort_capacity_among_more_long_bins_than_cus():

@@ -30,4 +30,4 @@ torch.cuda.synchronize()
 print("graphed iterations/s %.1f  (%.1f us per iteration, %d replays)" % (n / (time.perf_counter() - t0), 1e6 * (time.perf_counter() - t0) / n, n))
 gv.check()
 from topo4d_amd import rasterizer as R
-print("longest tile list over the cameras (warm-up, checked):", dict(R._LONGEST_BIN))
+print("longest tile list over the cameras (warm-up, checked):", {k: sc.longest_bin for k, sc in R._SCENES.items()})

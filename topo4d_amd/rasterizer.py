@@ -51,12 +51,57 @@ class GaussianRasterizationSettings(NamedTuple):
 # ------------------------------------------------------------------------------------------------------------
 _SYNC_MODE = "checked"
 _SYNC_MODE_EXPLICIT = False     # set_sync_mode() was called: until then the one-view drop-in (GaussianRasterizer) runs "auto"
-_CAPACITY = {}          # (device_index, P, H, W) -> learned per-view pair capacity
-_LONGEST_BIN = {}       # (device_index, P, H, W) -> longest tile list a checked forward has reported for this scene size
-_AUTO = {}              # (device_index, P, H, W, views key) -> _AutoTrack of the "auto" sync mode
-_AUTO_MAX = 256         # camera sets tracked at a time
 _BATCH_LOG = None       # when a list: every ViewBatch that runs a forward is appended (loop.GraphedViews keeps the batches
                         # of its captures to read their overflow flags back later)
+
+
+class _Scene:
+    """Everything the host remembers about ONE scene size (device, P, H, W) - the only two registries of this module are
+    `_SCENES` (these) and `_CAMERAS` (per settings object, below):
+      capacity     per-view pair-arena capacity learned so far (None: nothing learned yet; the first forward is checked)
+      longest_bin  longest tile list a checked forward has reported (None: unknown) -> the sort hints of `_flags`
+      tracks       camera set -> _AutoTrack of the "auto" sync mode (bounded: Topo4D builds new camera tuples every frame)
+      plans        launch shape (V, M, degree, scale modifier) -> _Plan (ctypes structures, byte sizes per capacity)"""
+    __slots__ = ("key", "capacity", "longest_bin", "tracks", "plans")
+    MAX_TRACKS = 256
+
+    def __init__(self, key):
+        self.key = key
+        self.capacity: Optional[int] = None
+        self.longest_bin: Optional[int] = None
+        self.tracks = {}
+        self.plans = {}
+
+    def grow(self, capacity: int) -> None:
+        self.capacity = max(self.capacity or 0, int(capacity))
+
+    def track_of(self, cam_key):
+        """(track, is_new) of a camera set; the oldest half is forgotten when the table is full (dicts keep insertion order)."""
+        t = self.tracks.get(cam_key)
+        if t is not None:
+            return t, False
+        if len(self.tracks) >= self.MAX_TRACKS:
+            for old in list(self.tracks)[: self.MAX_TRACKS // 2]:
+                del self.tracks[old]
+        t = self.tracks[cam_key] = _AutoTrack(self)
+        return t, True
+
+
+_SCENES = {}            # (device_index, P, H, W) -> _Scene
+
+
+def _scene(device_index, P: int, H: int, W: int) -> _Scene:
+    key = (device_index, int(P), int(H), int(W))
+    sc = _SCENES.get(key)
+    if sc is None:
+        sc = _SCENES[key] = _Scene(key)
+    return sc
+
+
+def _forget_scenes() -> None:
+    """Tests: drop everything learned about every scene size (capacities, sort hints, auto-mode tracks, pending statuses)."""
+    _SCENES.clear()
+    _PENDING.clear()
 
 
 class _Pending:
@@ -78,10 +123,10 @@ class _AutoTrack:
     value before its forward is enqueued; the forward's asynchronous device-to-host copy overwrites it, so "has it landed?"
     is two host loads - no event, no stream object on the per-iteration path."""
     RING = 8
-    __slots__ = ("pinned", "host", "args", "head", "count", "need", "key", "live")
+    __slots__ = ("pinned", "host", "args", "head", "count", "need", "scene", "live")
 
-    def __init__(self, key=None):
-        self.key = key                                  # (device_index, P, H, W) whose capacity this track feeds
+    def __init__(self, scene=None):
+        self.scene = scene                              # the _Scene whose capacity this track feeds
         self.pinned = torch.zeros(self.RING, 2, dtype=torch.int64).pin_memory()
         self.host = self.pinned.numpy()                 # same memory, cheap scalar reads
         base = self.pinned.data_ptr()
@@ -101,7 +146,7 @@ class _AutoTrack:
             poll_truncation()
             owner = self.live[self.head]
             if self.count == self.RING or (owner is not None and not owner.done):
-                dev_index = self.key[0] if self.key is not None else None
+                dev_index = self.scene.key[0] if self.scene is not None else None
                 torch.cuda.synchronize(dev_index)
                 # everything that was enqueued on that device has landed by now: harvest it (a truncated pass among them raises
                 # here); a slot that still reads "not yet" belongs to a forward that was never enqueued and can only be forgotten
@@ -141,8 +186,8 @@ def _harvest(entry: "_Pending"):
     entry.overflow, entry.need = bool(raw0 & 0xffffffff), (raw0 >> 32) & 0xffffffff
     track.need = max(track.need, entry.need)
     if entry.overflow:
-        if track.key is not None:
-            _CAPACITY[track.key] = max(_CAPACITY.get(track.key, 0), _round_capacity(track.need))
+        if track.scene is not None:
+            track.scene.grow(_round_capacity(track.need))
         return (entry.need, entry.cap)
     return None
 
@@ -170,8 +215,8 @@ def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = F
         while not wait_for.landed():
             if time.perf_counter() - t0 > 1.0:
                 # the device the forward ran on, not whichever is current
-                key = wait_for.track.key
-                torch.cuda.synchronize(key[0] if key is not None else None)
+                sc = wait_for.track.scene
+                torch.cuda.synchronize(sc.key[0] if sc is not None else None)
                 if not wait_for.landed():
                     # (a forward on a capturing stream, or one that never ran): no gradient of a render whose status is unknown
                     raise RuntimeError("topo4d_amd (sync_mode='auto'): the binning status of this backward's forward has not arrived "
@@ -181,8 +226,8 @@ def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = F
         entry = _PENDING[0]
         if not entry.landed():
             if _after_sync:
-                key = entry.track.key
-                if _synced_device is None or key is None or key[0] == _synced_device:
+                sc = entry.track.scene
+                if _synced_device is None or sc is None or sc.key[0] == _synced_device:
                     _PENDING.popleft()                  # can never land: its forward was not enqueued
                     entry.done = True
                     entry.track.count -= 1
@@ -262,8 +307,35 @@ def _round_capacity(n: int) -> int:
 # ------------------------------------------------------------------------------------------------------------
 # view records
 # ------------------------------------------------------------------------------------------------------------
-_VIEW_CACHE = OrderedDict()   # id(settings) -> (settings, versions, packed record); least recently used first
-_VIEW_CACHE_MAX = 512
+class _CameraRecord:
+    """What the host keeps per `GaussianRasterizationSettings` object (train.py:98 builds each camera once per frame and reuses
+    it for every iteration): the packed device record and - for the one-view drop-in - the call's constants."""
+    __slots__ = ("settings", "version", "record", "spec")
+
+    def __init__(self, settings, version, record):
+        self.settings, self.version, self.record, self.spec = settings, version, record, None
+
+
+_CAMERAS = OrderedDict()      # id(settings) -> _CameraRecord; least recently used first
+_CAMERAS_MAX = 512
+
+
+def _camera(s: GaussianRasterizationSettings, device, touch: bool = True) -> _CameraRecord:
+    key = id(s)
+    ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, device)
+    hit = _CAMERAS.get(key)
+    if hit is not None and hit.settings is s and hit.version == ver:
+        if touch:
+            _CAMERAS.move_to_end(key)                    # (one camera per call: the LRU order is refreshed on misses only)
+        return hit
+    rec = _CameraRecord(s, ver, _pack_one_view(s, device))
+    _CAMERAS[key] = rec
+    _CAMERAS.move_to_end(key)
+    # evict the least recently used entries only: whoever still holds a record (a ViewBatch, a captured HIP graph via
+    # loop.GraphedViews) keeps its own reference, so eviction can never free memory a pending launch reads
+    while len(_CAMERAS) > _CAMERAS_MAX:
+        _CAMERAS.popitem(last=False)
+    return rec
 
 
 def _pack_one_view(s: GaussianRasterizationSettings, device) -> torch.Tensor:
@@ -282,24 +354,7 @@ def _pack_one_view(s: GaussianRasterizationSettings, device) -> torch.Tensor:
 def pack_views(settings: Sequence[GaussianRasterizationSettings], device) -> torch.Tensor:
     """[V, T4D_VIEW_FLOATS] fp32 device records (layout: include/topo4d_raster.h).  Cached per settings object
     (train.py:98 builds each camera once per frame and reuses it for every iteration)."""
-    recs = []
-    for s in settings:
-        key = id(s)
-        ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, device)
-        hit = _VIEW_CACHE.get(key)
-        if hit is not None and hit[0] is s and hit[1] == ver:
-            if len(settings) > 1:
-                _VIEW_CACHE.move_to_end(key)             # (one camera per call: the LRU order is refreshed on misses only)
-            recs.append(hit[2])
-            continue
-        rec = _pack_one_view(s, device)
-        _VIEW_CACHE[key] = (s, ver, rec)
-        _VIEW_CACHE.move_to_end(key)
-        # evict the least recently used entries only: whoever still holds a record (a ViewBatch, a captured HIP graph via
-        # loop.GraphedViews) keeps its own reference, so eviction can never free memory a pending launch reads
-        while len(_VIEW_CACHE) > _VIEW_CACHE_MAX:
-            _VIEW_CACHE.popitem(last=False)
-        recs.append(rec)
+    recs = [_camera(s, device, touch=len(settings) > 1).record for s in settings]
     if len(recs) == 1:
         out = recs[0].unsqueeze(0)                           # a view of the cached record: no kernel, no allocation
     else:
@@ -344,7 +399,7 @@ def _raw_stream(device) -> int:
 
 
 class _Plan:
-    """Per (device, V, P, H, W, M, degree, scale modifier, flags) scratch of the host side: the ctypes structures of one call
+    """Per launch shape of a scene size (`_Scene.plans`: V, M, degree, scale modifier) scratch of the host side: the ctypes structures of one call
     are built once and refilled (a call only uses them while the C function runs), and the byte sizes the library reports for
     a given pair capacity are remembered - Topo4D calls the rasterizer thousands of times per frame with the same shapes."""
     __slots__ = ("fio", "bio", "status", "state_bytes", "scratch_bytes", "fio_ref", "bio_ref", "status_ref")
@@ -355,7 +410,6 @@ class _Plan:
         self.state_bytes, self.scratch_bytes = {}, {}
 
 
-_PLANS = {}
 _F32 = torch.float32
 
 
@@ -414,7 +468,7 @@ class ViewBatch:
             flags |= _lib.T4D_FLAG_RAW_PARAMS
         # tile lists of this scene size stayed well below the LDS sort buffer (2048) so far: skip the long-bin sort launch
         # (a speed hint only - see include/topo4d_raster.h)
-        longest = _LONGEST_BIN.get((self.device.index, P, self.H, self.W))
+        longest = _scene(self.device.index, P, self.H, self.W).longest_bin
         if longest is not None and longest > 1024:
             flags |= _lib.T4D_FLAG_LONG_LISTS     # some tile list bounds a small launch: the latency forward for up to 24 x CUs tiles
         if longest is not None and longest <= 1536:
@@ -468,34 +522,26 @@ class ViewBatch:
             radii = torch.empty((V, P), dtype=torch.int32, device=dev)
 
         mode = self.sync_mode or _SYNC_MODE
-        key = (dev.index, P, H, W)
-        cap = _CAPACITY.get(key)
-        known = cap is not None
-        if not known:
-            cap = _initial_capacity(P)
+        scene = _scene(dev.index, P, H, W)
+        known = scene.capacity is not None
+        cap = scene.capacity if known else _initial_capacity(P)
         checked = (mode == "checked") or self.debug or not known
         track = None
         if mode == "auto" and not self.debug:
             if _PENDING:
                 poll_truncation()                                 # statuses of every camera set that have landed by now
-                cap = _CAPACITY.get(key, cap)
-            akey = key + (self.cam_key,)
-            track = _AUTO.get(akey)
-            if track is None:
-                if len(_AUTO) >= _AUTO_MAX:                       # Topo4D builds new camera tuples every frame (train.py:98):
-                    for old in list(_AUTO)[: _AUTO_MAX // 2]:     # forget the oldest half (dicts keep insertion order)
-                        del _AUTO[old]
-                track = _AUTO[akey] = _AutoTrack(key)
+                cap = scene.capacity or cap
+            track, new_track = scene.track_of(self.cam_key)
+            if new_track:
                 checked = True                                    # first time these cameras see this scene size
             else:
                 if track.need > 0.75 * cap:                       # grow well before the arena can overflow
-                    cap = _round_capacity(track.need)
-                    _CAPACITY[key] = max(_CAPACITY.get(key, 0), cap)
-                cap = _CAPACITY.get(key, cap)
-        pkey = (dev.index, V, P, H, W, M, self.sh_degree, self.scale_modifier)
-        plan = _PLANS.get(pkey)
+                    scene.grow(_round_capacity(track.need))
+                cap = scene.capacity or cap
+        pkey = (V, M, self.sh_degree, self.scale_modifier)
+        plan = scene.plans.get(pkey)
         if plan is None:
-            plan = _PLANS[pkey] = _Plan()
+            plan = scene.plans[pkey] = _Plan()
         self.plan = plan
         status = plan.status
         lib = self.lib
@@ -537,8 +583,8 @@ class ViewBatch:
         if checked:
             # keep 1.5x head-room over what this scene needs so that lazy calls on nearby scenes fit
             want = _round_capacity(status.max_pairs_per_view)
-            _CAPACITY[key] = max(want, cap if key in _CAPACITY else 0)
-            _LONGEST_BIN[key] = max(_LONGEST_BIN.get(key, 0), int(status.max_tile_pairs))
+            scene.capacity = max(want, cap if scene.capacity is not None else 0)
+            scene.longest_bin = max(scene.longest_bin or 0, int(status.max_tile_pairs))
             if track is not None:
                 track.need = max(track.need, int(status.max_pairs_per_view))
             st = T4DStatus(status.max_pairs_per_view, status.total_pairs, status.overflow, status.max_tile_pairs)
@@ -749,23 +795,13 @@ def rasterize_views(settings: Sequence[GaussianRasterizationSettings], means3D, 
                                  _none_if_empty(scales), _none_if_empty(rotations), _none_if_empty(cov3D_precomp), spec)
 
 
-_SPECS = {}         # id(settings) -> (settings, view-record version, _CallSpec): the one-view drop-in's per-camera constants
-
-
 def _spec_of(s: GaussianRasterizationSettings, device) -> _CallSpec:
-    hit = _SPECS.get(id(s))
-    ver = (s.viewmatrix._version, s.projmatrix._version, s.campos._version, s.bg._version, device)
-    if hit is not None and hit[0] is s and hit[1] == ver:
-        return hit[2]
-    views = pack_views((s,), device)
-    debug = bool(s.debug)
-    spec = _CallSpec(views, int(s.image_height), int(s.image_width), float(s.scale_modifier), int(s.sh_degree), debug,
-                     bool(s.prefiltered), (id(s),), None, True)
-    if len(_SPECS) >= _VIEW_CACHE_MAX:                   # Topo4D builds new camera tuples every frame: forget the oldest half
-        for old in list(_SPECS)[: _VIEW_CACHE_MAX // 2]:
-            del _SPECS[old]
-    _SPECS[id(s)] = (s, ver, spec)
-    return spec
+    """The one-view drop-in's per-camera constants, kept in the camera's record."""
+    rec = _camera(s, device, touch=False)
+    if rec.spec is None:
+        rec.spec = _CallSpec(rec.record.unsqueeze(0), int(s.image_height), int(s.image_width), float(s.scale_modifier), int(s.sh_degree),
+                             bool(s.debug), bool(s.prefiltered), (id(s),), None, True)
+    return rec.spec
 
 
 try:
