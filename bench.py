@@ -572,9 +572,54 @@ def dense_1m_probe(dev, reps=5):
         kern = {n: round(1e3 * ms / c, 1) for n, (ms, c) in _lib.profile_end().items() if c}
     finally:
         topo4d_amd.rasterizer._restore_sync_mode(saved)
-    return {"workload": "1 view per call, P=1000000, 4096x3008 (WxH), opacity scenario A, forward+backward through the C ABI",
-            "ms_per_view": round(min(walls), 3), "ms_runs": [round(x, 3) for x in walls], "views_per_s": round(1e3 / min(walls), 1),
-            "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs), "kernels_us": kern}
+    out = {"workload": "1 view per call, P=1000000, 4096x3008 (WxH), opacity scenario A, forward+backward through the C ABI",
+           "ms_per_view": round(min(walls), 3), "ms_runs": [round(x, 3) for x in walls], "views_per_s": round(1e3 / min(walls), 1),
+           "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs), "kernels_us": kern}
+    del b, rv, dc
+    torch.cuda.empty_cache()
+    try:
+        out["texture_iteration"] = texture_iteration_probe(dev, p, cams[0], H, W)
+    except Exception as e:                                   # (never takes the render's numbers down with it)
+        out["texture_iteration"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def texture_iteration_probe(dev, p, cam, H, W, n_iters=10, reps=3):
+    """HOT LOOP 2 at its real size (train.py:729-741): pins on dense_rgb_colors -> render of the dense set -> 0.8 L1 + 0.2 (1-SSIM)
+    without the camera affine + 0.02 soft colour -> backward -> Adam, one full-resolution view per iteration, P = 10^6 at 4096 x 3008:
+    loop.optimise_dense_views chained by hand (no autograd).  ms per iteration, best of `reps` runs of `n_iters` iterations."""
+    import topo4d_amd
+    from topo4d_amd import loop as t4d_loop
+    from topo4d_amd.optim import FusedAdamPins
+    P = p["means3D"].shape[0]
+    params = {"dense_" + k: torch.nn.Parameter(v.to(dev).contiguous()) for k, v in p.items()}
+    params["dense_means3D"].requires_grad_(False)                                  # train.py:259-261
+    lrs = {"dense_means3D": 0.0, "dense_unnorm_rotations": 0.001, "dense_logit_opacities": 0.0, "dense_log_scales": 0.0,
+           "dense_rgb_colors": 0.0025}                                             # train.py:281-285
+    opt = FusedAdamPins([{"params": [v], "name": k, "lr": lrs[k]} for k, v in params.items()], eps=1e-15)
+    frozen = torch.zeros(P, dtype=torch.bool, device=dev)
+    frozen[::5] = True
+    opt.set_pin("dense_rgb_colors", frozen, 0.0)                                   # train.py:732-734
+    variables = {"dense_init_colors": params["dense_rgb_colors"].detach().clone()}
+    g = torch.Generator().manual_seed(1)
+    dataset = [{"cam": cam, "im": torch.rand(3, H, W, generator=g).to(dev), "id": 0, "mask": None}]
+    saved = topo4d_amd.rasterizer._save_sync_mode()
+    try:
+        topo4d_amd.set_sync_mode("auto")
+        t4d_loop.optimise_dense_views(params, variables, dataset, opt, n_iters=3, explicit=True)      # first call checked: learns the arena
+        torch.cuda.synchronize(dev)
+        runs = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            losses = t4d_loop.optimise_dense_views(params, variables, dataset, opt, n_iters=n_iters, explicit=True)
+            torch.cuda.synchronize(dev)
+            runs.append(1e3 * (time.perf_counter() - t0) / n_iters)
+    finally:
+        topo4d_amd.rasterizer._restore_sync_mode(saved)
+    return {"workload": "texture loop (train.py:729-741), P=1000000, one 4096x3008 view per iteration: pins -> render -> photometric loss "
+                        "(no affine) + 0.02 soft colour -> backward -> fused Adam; loop.optimise_dense_views, chained by hand",
+            "ms_per_iteration": round(min(runs), 3), "ms_runs": [round(x, 3) for x in runs], "it_per_s": round(1e3 / min(runs), 1),
+            "last_loss": round(float(losses[-1]), 6)}
 
 
 def loss_probe(dev):

@@ -359,3 +359,37 @@ def test_graphed_views_on_the_masked_branch_and_the_texture_loop():
     assert (pg['dense_rgb_colors'][frozen] != 0).any()
     with pytest.raises(ValueError):
         loop.GraphedViews(_dense_params(dense), dataset, FusedAdamPins(_groups(_dense_params(dense), dlrs), capturable=True), dense=True)
+
+
+def test_texture_iteration_at_the_texture_pass_size():
+    """HOT LOOP 2 at its real size: P = 10^6 dense Gaussians, one 4096 x 3008 view (helpers.py:608-609, README "4K images"): two
+    iterations of loop.optimise_dense_views chained by hand == through autograd bit for bit; nothing overflows (the soft-colour
+    kernel's grid, the one-view loss at 12 M pixels, the pair arena of a 48,128-tile view)."""
+    from tests import util
+    from scaffold import scene
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    H, W = 3008, 4096
+    p = scene.make_gaussians(1000, 1000, opacity="A", seed=0)
+    cam = util.to_device(scene.camera_rig(H, W, n_views=24)[12:13], "cuda")[0]
+    g = torch.Generator().manual_seed(2)
+    dataset = [{'cam': cam, 'im': torch.rand(3, H, W, generator=g).cuda(), 'id': 0, 'mask': None}]
+    lrs = {'dense_means3D': 0.0, 'dense_unnorm_rotations': 0.001, 'dense_logit_opacities': 0.0, 'dense_log_scales': 0.0, 'dense_rgb_colors': 0.0025}
+    frozen = torch.zeros(1000000, dtype=torch.bool, device="cuda"); frozen[::7] = True
+    res = []
+    for explicit in (True, False):
+        params = {"dense_" + k: torch.nn.Parameter(v.clone().cuda()) for k, v in p.items()}
+        params['dense_means3D'].requires_grad_(False)
+        variables = {'dense_init_colors': params['dense_rgb_colors'].detach().clone()}
+        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15)
+        opt.set_pin('dense_rgb_colors', frozen, 0.0)
+        mx = torch.zeros(1000000, device="cuda")
+        losses = loop.optimise_dense_views(params, variables, dataset, opt, n_iters=2, seed=0, max_2D_radius=mx, explicit=explicit)
+        res.append(({k: v.detach().clone() for k, v in params.items()}, torch.stack(losses), mx))
+        del params, opt
+        torch.cuda.empty_cache()
+    (pe, le, me), (pa, la, ma) = res
+    assert torch.isfinite(le).all() and torch.equal(le, la) and torch.equal(me, ma) and me.max() > 0
+    for k in pe:
+        assert torch.equal(pe[k], pa[k]), (k, (pe[k] - pa[k]).abs().max())
+    assert (pe['dense_rgb_colors'][frozen] != 0).any() and (pe['dense_rgb_colors'][~frozen] != p['rgb_colors'].cuda()[~frozen]).any()
