@@ -242,10 +242,14 @@ typedef struct T4DAdamTensor {
 #define T4D_ADAM_CLEAR_GRAD 1
 int t4d_adam_pin_step(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
                       void *hip_stream);
-/* The same step with its per-tensor hyper-parameters in DEVICE memory, so that the launch can be recorded in a HIP graph
- * and replayed: step_dev [n_tensors] int32 step counts (advanced by this call for the tensors that have a gradient, then
- * used for the bias corrections), lr_dev [n_tensors] float learning rates.  The `step` and `lr` fields of the descriptors
- * are ignored.  Bias corrections are evaluated in double precision on the device: results equal t4d_adam_pin_step's. */
+/* The same step with its hyper-parameters in DEVICE memory, so that the launch can be recorded in a HIP graph and replayed - ONE
+ * launch: lr_dev [n_tensors] float learning rates; step_dev [t4d_adam_step_counters(tensors, n)] int32 step counts, one PER WORKGROUP
+ * of the launch (workgroups of 256 elements, tensor after tensor in descriptor order: tensor k owns ceil(rows_k * width_k / 256)
+ * consecutive counters, all equal - read any of them).  A workgroup of a tensor that has a gradient advances its own counter, then
+ * uses it for the bias corrections (a tensor skipped for lack of a gradient does not advance).  The `step` and `lr` fields of the
+ * descriptors are ignored.  Bias corrections are evaluated in double precision on the device: results equal t4d_adam_pin_step's.
+ * The descriptors' shapes must be the same in every call that shares a step_dev array. */
+int64_t t4d_adam_step_counters(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors);
 int t4d_adam_pin_step_graph(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
                             int32_t *step_dev, const float *lr_dev, void *hip_stream);
 

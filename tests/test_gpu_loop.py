@@ -221,10 +221,74 @@ def test_explicit_graphed_iteration_is_the_autograd_capture_bit_for_bit():
     assert (pe['cam_m'] != p0['cam_m'].cuda()).any() and (pe['logit_opacities'] != p0['logit_opacities'].cuda()).any()
     assert gve._status_host is not None                 # one small view per launch: the status needed no copy node
     assert len(gve.means2D_grads) == 3 and gve.means2D_grads[0].shape == (240, 3)
-    with pytest.raises(ValueError):
+
+
+def test_hand_chained_iteration_composes_with_extra_loss_terms():
+    """Every iteration of the real loop carries topology regularisers on the parameters (train.py:330-368; out of scope as kernels).
+    The hand-chained iteration takes them as `extra_loss`: differentiated through autograd on their own, their gradients added to
+    the render's - one iteration's gradients and loss equal the all-autograd iteration's to rounding, the eager loop follows the
+    autograd loop, and GraphedViews records it (replays == the eager hand-chained loop)."""
+    import topo4d_amd
+    from tests import util
+    from scaffold import scene
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    H, W = 64, 80
+    p0 = scene.make_gaussians(12, 20, opacity="B", seed=3)
+    p0['log_scales'] = p0['log_scales'] + torch.randn(240, 3, generator=torch.Generator().manual_seed(9)) * 0.3
+    p0['cam_m'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(2)) * 0.05
+    p0['cam_c'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(3)) * 0.05
+    cams = util.to_device(scene.camera_rig(H, W, n_views=3), "cuda")
+    g = torch.Generator().manual_seed(5)
+    dataset = [{'cam': cams[i], 'im': torch.rand(3, H, W, generator=g).cuda(), 'id': i} for i in range(3)]
+    lrs = {'means3D': 1.6e-4, 'rgb_colors': 0.0025, 'unnorm_rotations': 0.001, 'logit_opacities': 0.05, 'log_scales': 0.001,
+           'cam_m': 1e-3, 'cam_c': 1e-3}
+    nb = torch.randint(0, 240, (240, 4), generator=g).cuda()
+    prev = p0['means3D'].cuda()
+
+    def regularisers(p, rv):                                   # iso / rot / scale terms shaped like train.py:340-361
+        off = rv['means3D'][nb] - rv['means3D'][:, None]
+        iso = (torch.sqrt((off ** 2).sum(-1) + 1e-20) - torch.sqrt(((prev[nb] - prev[:, None]) ** 2).sum(-1) + 1e-20)).abs().mean()
+        rot = ((rv['rotations'][nb] - rv['rotations'][:, None]) ** 2).sum(-1).mean()
+        return 20.0 * iso + 20.0 * rot + 10.0 * rv['scales'].min(dim=1).values.sum() + 1e-3 * p['cam_m'].pow(2).sum()
+
+    # one iteration: gradients and loss
+    pa = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+    pb = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
+    la, _, _ = loop.photometric_iteration(pa, dataset[1], extra_loss=regularisers)
+    la.backward()
+    lb, _, grads, _, _ = loop.explicit_iteration(pb, dataset[1], extra_loss=regularisers)
+    assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+    for k in pa:
+        scale = float(pa[k].grad.abs().max())
+        assert scale > 0 and (grads[k] - pa[k].grad).abs().max() <= 2e-6 * scale, (k, (grads[k] - pa[k].grad).abs().max(), scale)
+    # the loop, and the recorded loop
+    res = []
+    for mode in ("explicit", "autograd", "graphed"):
         params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in p0.items()}
-        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=True)
-        loop.GraphedViews(params, dataset, opt, extra_loss=lambda p, rv: p['means3D'].sum() * 0, explicit=True)
+        opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=(mode == "graphed"))
+        if mode == "graphed":
+            gv = loop.GraphedViews(params, dataset, opt, extra_loss=regularisers)
+            assert gv.explicit
+            topo4d_amd.set_sync_mode("lazy")
+            try:
+                rng, todo, losses = __import__("random").Random(4), [], []
+                for _ in range(8):
+                    curr, todo = loop.get_batch(todo, dataset, rng)
+                    losses.append(gv.step(curr['id']).clone())
+                gv.check()
+            finally:
+                topo4d_amd.set_sync_mode("checked")
+        else:
+            losses = loop.optimise_views(params, dataset, opt, n_iters=8, seed=4, extra_loss=regularisers, explicit=(mode == "explicit"))
+        res.append(({k: v.detach().clone() for k, v in params.items()}, torch.stack(losses)))
+    (pe, le), (pa_, la_), (pg, lg) = res
+    assert torch.allclose(le, la_, rtol=2e-5, atol=1e-7), (le, la_)
+    assert torch.allclose(le, lg, rtol=2e-6, atol=1e-8), (le, lg)
+    for k in pe:
+        moved = (pa_[k] - p0[k].cuda()).abs()
+        assert ((pe[k] - pa_[k]).abs() <= 0.02 * moved + 3e-5).float().mean() > 0.97, k
+        assert ((pe[k] - pg[k]).abs() <= 0.02 * moved + 3e-5).float().mean() > 0.97, k
 
 
 def test_explicit_eager_loop_is_the_autograd_loop_bit_for_bit():

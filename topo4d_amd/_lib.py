@@ -32,7 +32,7 @@ EXPORTS = (
     "t4d_debug_state_layout", "t4d_profile_begin", "t4d_profile_end", "t4d_view_dot", "t4d_view_dot_scratch_bytes",
     "t4d_texture_bake", "t4d_texture_render_colors", "t4d_texture_bake_scratch_bytes", "t4d_photometric_loss", "t4d_photometric_scratch_bytes",
     "t4d_masked_l1_loss", "t4d_masked_l1_scratch_bytes",
-    "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
+    "t4d_adam_pin_step", "t4d_adam_pin_step_graph", "t4d_adam_step_counters", "t4d_dense_interpolate", "t4d_activate_forward", "t4d_activate_backward",
     "t4d_sum_views", "t4d_label_mask_target", "t4d_soft_color_loss", "t4d_soft_color_scratch_bytes",
 )
 
@@ -151,6 +151,8 @@ def load():
                                         C.c_size_t, C.c_void_p]
     lib.t4d_adam_pin_step.restype = C.c_int
     lib.t4d_adam_pin_step.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    lib.t4d_adam_step_counters.restype = C.c_int64
+    lib.t4d_adam_step_counters.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32]
     lib.t4d_adam_pin_step_graph.restype = C.c_int
     lib.t4d_adam_pin_step_graph.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                             C.c_void_p]

@@ -28,18 +28,11 @@ struct AdamArgs {
     long long first_block[kMaxTensors + 1];    // exclusive prefix of the per-tensor block counts
     float step_size[kMaxTensors];              // lr / (1 - beta1^t)                (host-side hyper-parameters)
     float inv_bc2_sqrt[kMaxTensors];           // 1 / sqrt(1 - beta2^t)
-    const int32_t *step_dev;                   // device-side hyper-parameters (graph replays): step counts, already advanced
+    int32_t *step_dev;                         // device-side hyper-parameters (graph replays): one step counter PER WORKGROUP of the launch
     const float *lr_dev;
     int n;
     float beta1, beta2, eps;
 };
-
-// advances the device-side step counters of the tensors that take a gradient step (one thread per tensor)
-__global__ void k_adam_tick(int32_t *step_dev, const uint32_t has_grad_mask, const int n)
-{
-    const int k = threadIdx.x;
-    if (k < n && ((has_grad_mask >> k) & 1u)) step_dev[k] += 1;
-}
 
 template <bool DEV>
 __global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
@@ -54,7 +47,12 @@ __global__ __launch_bounds__(kBlock) void k_adam_pin(const AdamArgs A)
         // same double-precision bias corrections as the host path, from the counters kept in device memory
         __shared__ float s_hyper[2];
         if (threadIdx.x == 0) {
-            const double st = T.grad ? (double)A.step_dev[k] : 1.0;
+            // Every workgroup keeps its OWN copy of its tensor's step count and advances it itself: no tick launch in front of the
+            // step (a kernel that does nothing still lasts 4.5 us between its neighbours in a replayed graph), no race - nobody
+            // else touches this word - and all copies of a tensor agree because they all count the same launches.
+            int32_t st_i = A.step_dev[blockIdx.x];
+            if (T.grad) { st_i += 1; A.step_dev[blockIdx.x] = st_i; }
+            const double st = T.grad ? (double)st_i : 1.0;
             const double bc1 = 1.0 - pow((double)A.beta1, st), bc2 = 1.0 - pow((double)A.beta2, st);
             s_hyper[0] = (float)((double)A.lr_dev[k] / bc1);
             s_hyper[1] = (float)(1.0 / sqrt(bc2));
@@ -112,7 +110,6 @@ int adam_launch(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, fl
     if (blocks == 0) return T4D_OK;
     if (blocks > 0x7fffffffLL) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: too many elements%s", "");
     if (step_dev) {
-        hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, step_dev, has_grad, (int)n_tensors);
         hipLaunchKernelGGL(k_adam_pin<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, A);
     } else {
         hipLaunchKernelGGL(k_adam_pin<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)hip_stream, A);
@@ -128,6 +125,14 @@ T4D_EXPORT int t4d_adam_pin_step(const T4DAdamTensor *tensors, int32_t n_tensors
                                  void *hip_stream)
 {
     return adam_launch(tensors, n_tensors, beta1, beta2, eps, nullptr, nullptr, hip_stream);
+}
+
+T4D_EXPORT int64_t t4d_adam_step_counters(const T4DAdamTensor *tensors, int32_t n_tensors)
+{
+    if (!tensors || n_tensors < 1 || n_tensors > kMaxTensors) return 0;
+    long long blocks = 0;
+    for (int k = 0; k < n_tensors; k++) blocks += (tensors[k].rows * tensors[k].width + kBlock - 1) / kBlock;
+    return (int64_t)blocks;
 }
 
 T4D_EXPORT int t4d_adam_pin_step_graph(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps,

@@ -148,7 +148,7 @@ def dense_iteration(params, variables, curr_data, loss_fn: Optional[Callable] = 
 # one iteration chained by hand (no autograd)
 # ------------------------------------------------------------------------------------------------------------
 def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None, target: Optional[torch.Tensor] = None,
-                       dense: bool = False, soft_color=None):
+                       dense: bool = False, soft_color=None, extra_loss: Optional[Callable] = None):
     """photometric_iteration (or, with `dense`, dense_iteration) + loss.backward() WITHOUT autograd: t4d_rasterize_forward,
     t4d_photometric_loss, t4d_rasterize_backward chained by hand - the activations and their backward inside the rasterizer
     (T4D_FLAG_RAW_PARAMS: the arithmetic of t4d_activate_forward / t4d_activate_backward, no launch of their own) - and none of
@@ -159,6 +159,11 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None, targ
     `target`: the image to compare with (target_image(...); default curr_data['im']).
     `dense`: the dense_* parameters, no camera affine (get_loss_dense); `soft_color` = (dense_init_colors, weight) adds
     weight * l1_loss_v2 to the loss and its gradient to dL/d dense_rgb_colors (t4d_soft_color_loss).
+    `extra_loss(params, rendervar) -> scalar`: further loss terms on the parameters (Topo4D's topology regularisers, train.py:330-368,
+    which EVERY iteration of the real loop carries) - differentiated through autograd on their own (the fused activations give them
+    `rendervar`), their gradients ADDED to the render's hand-chained ones: the photometric part of the iteration still runs without
+    autograd.  (The sum of two gradients is order-independent; a parameter with more extra terms than one is summed in autograd's
+    order: equal to the all-autograd iteration to rounding, not bit for bit.)
     `cam_grads`: {'cam_m': [n_cams, 3], 'cam_c': ...} persistent ZERO buffers; the loss kernel writes row `id` of each.
     `status_sink`: data pointer of 16 bytes of pinned host memory for the forward's status block (ViewBatch.status_sink).
     Returns (loss: device scalar, radius, grads: {parameter name: gradient tensor} for the parameters that require a gradient,
@@ -216,6 +221,20 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None, targ
                 full = torch.zeros_like(params[k])
                 full[cid:cid + 1] = row
                 grads[k] = full
+    if extra_loss is not None:
+        with torch.enable_grad():
+            rendervar = params2rendervar_fused(_dense_view(params) if dense else params)
+            l_extra = extra_loss(params, rendervar)
+            names = [k for k, p in params.items() if isinstance(p, torch.Tensor) and p.requires_grad]
+            g_extra = torch.autograd.grad(l_extra, [params[k] for k in names], allow_unused=True)
+        for k, ge in zip(names, g_extra):
+            if ge is None:
+                continue
+            if k in grads:
+                grads[k].add_(ge)                         # (cam_m / cam_c: the persistent buffer the Adam step clears)
+            else:
+                grads[k] = ge
+        total = total + l_extra.detach()
     return total, radius, grads, batch, g['means2D']
 
 
@@ -269,9 +288,9 @@ def explicit_frame_iteration(params, frame: List[dict], gt: Optional[torch.Tenso
 # ------------------------------------------------------------------------------------------------------------
 # the loops
 # ------------------------------------------------------------------------------------------------------------
-def _can_chain(params, optimizer, keys, loss_fn, extra_loss) -> bool:
+def _can_chain(params, optimizer, keys, loss_fn) -> bool:
     from .optim import FusedAdamPins
-    return loss_fn is None and extra_loss is None and isinstance(optimizer, FusedAdamPins) and all(k in params for k in keys) \
+    return loss_fn is None and isinstance(optimizer, FusedAdamPins) and all(k in params for k in keys) \
         and ('cam_m' in params) == ('cam_c' in params) and params[keys[0]].is_cuda
 
 
@@ -296,25 +315,27 @@ def optimise_views(params, dataset: List[dict], optimizer, n_iters: int, seed: i
     """train.py:661-673 for `n_iters` iterations.  Returns the list of per-iteration losses (device scalars, no sync).
     `use_mask`, `is_initial_timestep`: get_loss's branch (train.py:315-327; Topo4D runs use_mask=True, i.e. the masked target in
     every frame after the first - `label_colors` as in prepare_masked_targets, which is called here once).
-    `explicit` (default: when possible - fused loss, no extra loss, a FusedAdamPins optimiser, the scale + rotation / RGB
-    parametrisation): every iteration is chained by hand (explicit_iteration) instead of going through autograd - same
-    arithmetic, a third of the host time."""
+    `explicit` (default: when possible - fused loss, a FusedAdamPins optimiser, the scale + rotation / RGB parametrisation): the
+    render, its loss and its backward are chained by hand (explicit_iteration) instead of going through autograd - same
+    arithmetic, a third of the host time; `extra_loss` terms (the regularisers of train.py:330-368) are differentiated on their
+    own and their gradients added."""
     rng = Random(seed)
     todo: list = []
     losses = []
     masked = use_mask and not is_initial_timestep
     if masked:
         prepare_masked_targets(dataset, label_colors)
-    can = _can_chain(params, optimizer, _RENDER_KEYS, loss_fn, extra_loss)
+    can = _can_chain(params, optimizer, _RENDER_KEYS, loss_fn)
     if explicit and not can:
-        raise ValueError("explicit=True needs the fused loss, no extra_loss, a FusedAdamPins optimiser and the parameters " + ", ".join(_RENDER_KEYS))
+        raise ValueError("explicit=True needs the fused loss, a FusedAdamPins optimiser and the parameters " + ", ".join(_RENDER_KEYS))
     if can if explicit is None else explicit:
         before = set(optimizer.clear_grad)
         cam_grads = _adopt_cam_grads(params, optimizer)
         try:
             for _ in range(n_iters):
                 curr, todo = get_batch(todo, dataset, rng)
-                l, radius, grads, _, _ = explicit_iteration(params, curr, cam_grads, target=curr['masked_im'] if masked else None)
+                l, radius, grads, _, _ = explicit_iteration(params, curr, cam_grads, target=curr['masked_im'] if masked else None,
+                                                            extra_loss=extra_loss)
                 for k, gr in grads.items():
                     params[k].grad = gr
                 optimizer.step()
@@ -353,7 +374,7 @@ def optimise_dense_views(params, variables, dataset: List[dict], optimizer, n_it
     todo: list = []
     losses = []
     fused_opt = isinstance(optimizer, FusedAdamPins)
-    can = _can_chain(params, optimizer, _DENSE_KEYS, loss_fn, None) and soft_color_fn is None and pre_iteration is None
+    can = _can_chain(params, optimizer, _DENSE_KEYS, loss_fn) and soft_color_fn is None and pre_iteration is None
     if explicit and not can:
         raise ValueError("explicit=True needs the fused losses, no pre_iteration callable, a FusedAdamPins optimiser and the parameters " + ", ".join(_DENSE_KEYS))
     chain = can if explicit is None else explicit
@@ -422,13 +443,14 @@ class GraphedViews:
             raise RuntimeError("GraphedViews runs on the GPU only")
         # explicit: the iteration chained by hand (explicit_iteration) instead of recorded through autograd - the same
         # arithmetic without autograd's fill / copy / multiply launches (parameters after any number of steps are bit-identical,
-        # tests/test_gpu_loop.py).  Needs the fused loss, no extra loss term and the scale + rotation / RGB parametrisation.
-        can = loss_fn is None and extra_loss is None and all(k in params for k in keys) and ('cam_m' in params) == ('cam_c' in params)
+        # tests/test_gpu_loop.py).  Needs the fused loss and the scale + rotation / RGB parametrisation; an extra loss term is
+        # differentiated on its own inside the recorded iteration and its gradients added.
+        can = loss_fn is None and all(k in params for k in keys) and ('cam_m' in params) == ('cam_c' in params)
         if explicit and not can:
-            raise ValueError("explicit=True needs the fused loss, no extra_loss, and the parameters " + ", ".join(keys))
+            raise ValueError("explicit=True needs the fused loss and the parameters " + ", ".join(keys))
         self.explicit = can if explicit is None else bool(explicit)
         if dense and not self.explicit:
-            raise ValueError("GraphedViews(dense=True) records the hand-chained iteration only (fused losses, no extra_loss)")
+            raise ValueError("GraphedViews(dense=True) records the hand-chained iteration only (fused losses)")
         self._loss_fn, self._extra_loss = loss_fn, extra_loss
         self._cam_grads = None
         self._clear_before = set(optimizer.clear_grad)
@@ -516,7 +538,8 @@ class GraphedViews:
             l, radius, grads, batch, g2d = explicit_iteration(self.params, data, None, sink, target=self._targets[i], dense=True,
                                                               soft_color=(self.variables['dense_init_colors'], self.soft_color_weight))
         else:
-            l, radius, grads, batch, g2d = explicit_iteration(self.params, data, self._cam_grads, sink, target=self._targets[i])
+            l, radius, grads, batch, g2d = explicit_iteration(self.params, data, self._cam_grads, sink, target=self._targets[i],
+                                                              extra_loss=self._extra_loss)
         for k, gr in grads.items():
             self.params[k].grad = gr
         self.opt.step(pins=not self.dense)

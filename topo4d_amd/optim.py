@@ -43,9 +43,19 @@ class FusedAdamPins:
         self._lr_dev: Optional[torch.Tensor] = None
         self._lr_host: Optional[List[float]] = None
 
+    def _counter_layout(self):
+        """First step counter of every tensor and their total: the fused step keeps one counter per workgroup of 256 elements,
+        tensor after tensor in group order (t4d_adam_step_counters)."""
+        first, n = [], 0
+        for g in self.param_groups:
+            first.append(n)
+            n += (g["params"][0].numel() + 255) // 256
+        return first, n
+
     def _hyper(self, dev):
         if self._step_dev is None:
-            self._step_dev = torch.zeros(len(self.param_groups), dtype=torch.int32, device=dev)
+            _, n = self._counter_layout()
+            self._step_dev = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
             self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
         return self._step_dev, self._lr_dev
 
@@ -62,7 +72,9 @@ class FusedAdamPins:
     def steps(self) -> List[int]:
         """Per-tensor step counts (synchronising read in capturable mode)."""
         if self.capturable and self._step_dev is not None:
-            return [int(x) for x in self._step_dev.tolist()]
+            first, _ = self._counter_layout()
+            host = self._step_dev.tolist()
+            return [int(host[f]) if g["params"][0].numel() > 0 else 0 for f, g in zip(first, self.param_groups)]
         return [int(self.state.get(g["params"][0], {}).get("step", 0)) for g in self.param_groups]
 
     # -- pins ------------------------------------------------------------------------------------------------
