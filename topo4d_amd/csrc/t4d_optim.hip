@@ -91,14 +91,12 @@ int adam_launch(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, fl
     A.n = n_tensors; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
     A.step_dev = step_dev; A.lr_dev = lr_dev;
     long long blocks = 0;
-    uint32_t has_grad = 0;
     for (int k = 0; k < n_tensors; k++) {
         const T4DAdamTensor &t = tensors[k];
         if (!t.param || t.rows < 0 || t.width < 1 || (t.grad && (!t.exp_avg || !t.exp_avg_sq)) || ((t.pin_mask == nullptr) != (t.pin_values == nullptr)))
             return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: inconsistent tensor descriptor%s", "");
         if (!step_dev && t.grad && t.step < 1) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step: step must be >= 1%s", "");
         A.t[k] = t;
-        if (t.grad) has_grad |= 1u << k;
         const double st = t.grad ? (double)t.step : 1.0;
         const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
         A.step_size[k] = (float)((double)t.lr / bc1);

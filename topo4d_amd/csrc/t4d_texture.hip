@@ -43,6 +43,9 @@ struct Tri {                                // 80 bytes = five 16-byte words: th
 };
 static_assert(sizeof(Tri) == 80, "Tri must stay five float4 words");
 constexpr int kScanChunk = 1024;
+#ifndef T4D_TEX_GROUP
+#define T4D_TEX_GROUP 16               // lanes per triangle record in the texel loop (same box: 64 lanes 0.679 ms, 32: 0.638, 16: 0.622, 8: 0.640)
+#endif
 #ifndef T4D_TEX_ABL
 #define T4D_TEX_ABL 0                // timing experiments only (results wrong): 1 = no per-triangle texel loop, 2 = the write-out stores one float per texel
 #endif
@@ -366,24 +369,35 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
             }
             __syncthreads();
         }
-        for (int k = wave; k < ((T4D_TEX_ABL & 1) ? 0 : cnt); k += kBlock / 64) {           // wave-uniform: one record per wave at a time
-            const Tri t = s_tri[k];
+        // FOUR records per wave at a time, sixteen lanes each: a triangle of a UV mesh baked at 8 texels per edge has a clipped box of
+        // 64-81 texels, so a whole wave per record spent its second pass on 0-17 of 64 lanes (8192^2: 2.1 M triangles x 128 lane
+        // slots for 170 M box texels); sixteen lanes per record take the same box in 4-6 passes of 16 (64-96 slots).  Which lane
+        // evaluates a texel does not matter: the LDS maximum is order-independent.
+        constexpr int kG = T4D_TEX_GROUP, kPerWave = 64 / kG;             // lanes per record, records per wave at a time
+        const int half = lane / kG, hl = lane % kG;
+        for (int k0 = kPerWave * wave; k0 < ((T4D_TEX_ABL & 1) ? 0 : cnt); k0 += kPerWave * (kBlock / 64)) {
+            const int k = k0 + half;
+            const bool have = k < cnt;
+            const Tri t = s_tri[have ? k : k0];
             const int x_lo = max(t.x_min, tx0), x_hi = min(t.x_max, rx_hi), y_lo = max(t.y_min, ry_lo), y_hi = min(t.y_max, ry_hi);
             const int rw = x_hi - x_lo + 1, rh = y_hi - y_lo + 1;
-            if (rw <= 0 || rh <= 0) continue;
-            const int npx = rw * rh;
+            const int npx = (have && rw > 0 && rh > 0) ? rw * rh : 0;
+            int nmax = 0;                                                                                     // wave-uniform trip count
+#pragma unroll
+            for (int g = 0; g < kPerWave; g++) nmax = max(nmax, __builtin_amdgcn_readlane(npx, g * kG));
             const uint32_t tag = fast ? (uint32_t)k : (uint32_t)t.idx;     // sorted slot or triangle index: lower wins on equal depth
             // p / rw without an integer division (~25 instructions per texel, a fifth of this loop): rw <= 32 and p < 1,024, so the
             // 16-bit fixed-point reciprocal m >= 65536 / rw with m rw - 65536 <= rw gives the exact quotient (p (m rw - 65536) < 65536)
-            const uint32_t m_rw = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)rw)) + 1u;
-            for (int p = lane; p < npx; p += 64) {
+            const uint32_t m_rw = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(rw, 1))) + 1u;
+            for (int p = hl; p < nmax; p += kG) {
+                if (p >= npx) continue;
                 const int dy = (int)(((uint32_t)p * m_rw) >> 16), x = x_lo + (p - dy * rw), y = y_lo + dy;
                 const float px = (float)x, py = (float)y;
                 const bool border = tile_border && (px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3);      // mesh_core.cpp:211
                 const TriEval ev = eval_texel(t, px, py, border);
                 // `pd > depth_buffer` against the caller's buffer first (also drops NaN); later rivals meet in the LDS maximum
-                const float have = FRESH ? kFreshDepth : s_depth[(y - ty0) * kTile + (x - tx0)];
-                if (ev.pass && ev.pd > have)
+                const float have_d = FRESH ? kFreshDepth : s_depth[(y - ty0) * kTile + (x - tx0)];
+                if (ev.pass && ev.pd > have_d)
                     atomicMax(&s_key[(y - ty0) * kTile + (x - tx0)], ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~tag);
             }
         }
@@ -392,7 +406,10 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
     // The image is [h, w, c]: a texel's c floats sit 4c bytes from its neighbour's; consecutive lanes therefore take
     // consecutive texels of a tile row (the stores of a wave cover whole cache lines between them).
     if (fast) {
-        // the winner's record and colours are still in LDS: same record, same operations as in the loop above
+        // the winner's record and colours are still in LDS: same record, same operations as in the loop above.
+        // (Measured and dropped in round 5: staging a whole FRESH tile's colours in 12 KB of LDS and writing them as 16-byte stores
+        // instead of three 4-byte stores per lane at a 12-byte stride - 0.622 -> 0.754 ms for the 8192^2 bake: the 37 KB of LDS
+        // leave four workgroups per CU where six ran, and the tile pays one more barrier.)
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
             const int e = tid + j * kBlock;

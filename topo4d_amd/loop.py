@@ -155,7 +155,7 @@ def explicit_iteration(params, curr_data, cam_grads=None, status_sink=None, targ
     the launches autograd puts around them (the zeros + 0 of means2D, ones_like for the root, a fill and a copy for every
     `[cid]` / `[0]` it differentiates through, the multiplication of dL/dim by a cotangent of one: nine launches of 4-5 us per
     iteration, a third of a 148 us graphed iteration).  For the precomputed-RGB, scale + rotation parametrisation of
-    train.py:303-315 / :385-393 with the fused loss and no extra loss term.
+    train.py:303-315 / :385-393 with the fused loss.
     `target`: the image to compare with (target_image(...); default curr_data['im']).
     `dense`: the dense_* parameters, no camera affine (get_loss_dense); `soft_color` = (dense_init_colors, weight) adds
     weight * l1_loss_v2 to the loss and its gradient to dL/d dense_rgb_colors (t4d_soft_color_loss).
