@@ -31,7 +31,7 @@ namespace {
 constexpr int kTile = 32;        // bin = workgroup tile: 32x32 texels, four per thread (the dependent-load chain of a workgroup -
                                  // bin header -> records -> colours - is then paid once per 1024 texels: at 16x16 the kernel was bound by it)
 constexpr int kBlock = 256;
-constexpr int kStage = 128;      // triangles set up in LDS per round
+constexpr int kStage = 120;      // triangles set up in LDS per round: 120 x (64 + 36) B + 8 KiB of keys = 20.2 KB per workgroup, eight per CU
 
 struct Tri {                                // 80 bytes = five 16-byte words: the unit of the per-tile lists
     float p0x, p0y, v0x, v0y, v1x, v1y;     // p0, v0 = p2 - p0, v1 = p1 - p0
@@ -220,10 +220,24 @@ __device__ __forceinline__ uint32_t depth_order_bits(const float d)      // a > 
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// What the texel loop and the write-out read per staged triangle: 64 bytes = four 16-byte words (the set-up record `Tri` without the
+// vertex indices, its box already clipped to the tile and packed as texel offsets inside it).
+struct __attribute__((aligned(16))) TriRec {
+    float p0x, p0y, v0x, v0y, v1x, v1y;
+    float dot00, dot01, dot11, inverDeno;
+    float d0, d1, d2;
+    uint32_t box;                           // x_lo | x_hi << 8 | y_lo << 16 | y_hi << 24, relative to the tile; x_lo > x_hi: no texel here
+    int idx;
+    int pad;
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must stay four float4 words");
+constexpr uint32_t kEmptyBox = 1u;          // x_lo = 1, x_hi = 0
+
 struct TriEval { float w0, w1, w2, pd; bool pass; };
 
 // mesh_core.cpp:201-216 for one (triangle record, texel): barycentric weights, the in-triangle / border-ring test, depth
-__device__ __forceinline__ TriEval eval_texel(const Tri &t, const float px, const float py, const bool border)
+template <class TRI>
+__device__ __forceinline__ TriEval eval_texel(const TRI &t, const float px, const float py, const bool border)
 {
 #pragma clang fp contract(off)
     TriEval r;
@@ -287,16 +301,20 @@ __device__ __forceinline__ void setup_triangle(const TexP &P, const int i, Tri &
 // their vertex colours, and the write-out reads the winner's record from LDS instead of gathering triangle -> vertices ->
 // colours per texel (1.0 of the 1.48 ms of the 8192^2 bake in round 2).
 constexpr float kFreshDepth = -999999.0f;
-constexpr int kMaxC = 4;                                 // colour channels the fast path stages (Topo4D: 3)
+constexpr int kMaxC = 3;                                 // colour channels the fast path stages (Topo4D: 3; more take the general path)
 
 template <bool FRESH>
-__global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
+// Eight waves per SIMD (at most 64 registers; it took 78 and ran six): the tile is a chain of dependent fetches - bin header, list,
+// triangles, vertices, colours - and what hides it is other workgroups.  8192^2 bake on one box: 0.618 ms at six, 0.590 at seven, 0.563 at eight.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 8 : 6, FRESH ? 8 : 6))) void k_tex_render(const TexP P)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) Tri s_tri[kStage];
+    __shared__ TriRec s_tri[kStage];
     __shared__ float s_col[kStage][3][kMaxC];
-    __shared__ uint32_t s_idx[2][kStage];
     __shared__ unsigned long long s_key[kTile * kTile];
+    // the two index arrays of the rank sort live in the keys' memory: the sort is over before the keys are zeroed
+    uint32_t (*s_idx)[kStage] = reinterpret_cast<uint32_t (*)[kStage]>(s_key);
+    static_assert(2 * kStage * sizeof(uint32_t) <= sizeof(unsigned long long) * kTile * kTile, "s_idx must fit into s_key");
     __shared__ float s_depth[FRESH ? 1 : kTile * kTile];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
@@ -323,13 +341,18 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
     const uint32_t off = P.bin_off[b];
     // (only the tiles along the image's edge hold texels of the 2-pixel border ring: the others skip the four compares per texel)
     const bool tile_border = tx0 < 2 || ty0 < 2 || tx0 + kTile > P.w - 3 || ty0 + kTile > P.h - 3;
-    for (int e = tid; e < kTile * kTile; e += kBlock) {           // the caller's depth buffer for this tile: read once, tested from LDS
-        s_key[e] = 0ull;
-        if (!FRESH) {
-            const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
-            s_depth[e] = (x <= rx_hi && y >= ry_lo && y <= ry_hi) ? P.depth[(size_t)y * P.w + x] : 0.f;
-        }
-    }
+    // the staged record of triangle record `t`: its box clipped to this tile (and band) once, here, instead of in every wave that takes it
+    auto make_rec = [&](const Tri &t) {
+        TriRec r;
+        r.p0x = t.p0x; r.p0y = t.p0y; r.v0x = t.v0x; r.v0y = t.v0y; r.v1x = t.v1x; r.v1y = t.v1y;
+        r.dot00 = t.dot00; r.dot01 = t.dot01; r.dot11 = t.dot11; r.inverDeno = t.inverDeno;
+        r.d0 = t.d0; r.d1 = t.d1; r.d2 = t.d2;
+        const int x_lo = max(t.x_min, tx0), x_hi = min(t.x_max, rx_hi), y_lo = max(t.y_min, ry_lo), y_hi = min(t.y_max, ry_hi);
+        r.box = (x_hi < x_lo || y_hi < y_lo) ? kEmptyBox
+                                             : (uint32_t)(x_lo - tx0) | (uint32_t)(x_hi - tx0) << 8 | (uint32_t)(y_lo - ty0) << 16 | (uint32_t)(y_hi - ty0) << 24;
+        r.idx = t.idx; r.pad = 0;
+        return r;
+    };
     const bool fast = n <= (uint32_t)kStage && P.c <= kMaxC && off + n <= P.cap;
     if (fast) {
         // ---- rank-sort the list by triangle index (indices are unique inside a bin)
@@ -343,20 +366,29 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
         }
         __syncthreads();
         // ---- records + vertex colours of every triangle of the tile
-        if (tid < (int)n) {
-            const int i = (int)s_idx[1][tid];
+        int my_tri = -1;
+        if (tid < (int)n) my_tri = (int)s_idx[1][tid];
+        __syncthreads();                                           // (the index arrays share the keys' memory: done with them)
+        if (my_tri >= 0) {
             Tri t;
-            setup_triangle(P, i, t);
-            s_tri[tid] = t;
-            const int i2 = P.triangles[3 * (size_t)i + 2];
+            setup_triangle(P, my_tri, t);
+            s_tri[tid] = make_rec(t);
+            const int i2 = P.triangles[3 * (size_t)my_tri + 2];
             for (int k = 0; k < P.c; k++) {
                 s_col[tid][0][k] = P.colors[(size_t)P.c * t.i0 + k];
                 s_col[tid][1][k] = P.colors[(size_t)P.c * t.i1 + k];
                 s_col[tid][2][k] = P.colors[(size_t)P.c * i2 + k];
             }
         }
-        __syncthreads();
     }
+    for (int e = tid; e < kTile * kTile; e += kBlock) {           // the caller's depth buffer for this tile: read once, tested from LDS
+        s_key[e] = 0ull;
+        if (!FRESH) {
+            const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+            s_depth[e] = (x <= rx_hi && y >= ry_lo && y <= ry_hi) ? P.depth[(size_t)y * P.w + x] : 0.f;
+        }
+    }
+    __syncthreads();
     for (uint32_t base = 0; base < n; base += kStage) {
         const int cnt = (int)min((uint32_t)kStage, n - base);
         if (!fast) {
@@ -365,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
                 Tri t;
                 if (off + base + tid < P.cap) setup_triangle(P, (int)P.list[off + base + tid], t);
                 else { memset(&t, 0, sizeof(t)); t.x_min = 1; t.x_max = 0; t.y_min = 1; t.y_max = 0; t.idx = 0x7fffffff; }     // matches no texel
-                s_tri[tid] = t;
+                s_tri[tid] = make_rec(t);
             }
             __syncthreads();
         }
@@ -374,14 +406,14 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
         // slots for 170 M box texels); sixteen lanes per record take the same box in 4-6 passes of 16 (64-96 slots).  Which lane
         // evaluates a texel does not matter: the LDS maximum is order-independent.
         constexpr int kG = T4D_TEX_GROUP, kPerWave = 64 / kG;             // lanes per record, records per wave at a time
-        const int half = lane / kG, hl = lane % kG;
+        const int grp = lane / kG, hl = lane % kG;
         for (int k0 = kPerWave * wave; k0 < ((T4D_TEX_ABL & 1) ? 0 : cnt); k0 += kPerWave * (kBlock / 64)) {
-            const int k = k0 + half;
+            const int k = k0 + grp;
             const bool have = k < cnt;
-            const Tri t = s_tri[have ? k : k0];
-            const int x_lo = max(t.x_min, tx0), x_hi = min(t.x_max, rx_hi), y_lo = max(t.y_min, ry_lo), y_hi = min(t.y_max, ry_hi);
-            const int rw = x_hi - x_lo + 1, rh = y_hi - y_lo + 1;
-            const int npx = (have && rw > 0 && rh > 0) ? rw * rh : 0;
+            const TriRec t = s_tri[have ? k : k0];
+            const int bx_lo = (int)(t.box & 0xffu), bx_hi = (int)((t.box >> 8) & 0xffu), by_lo = (int)((t.box >> 16) & 0xffu), by_hi = (int)(t.box >> 24);
+            const int rw = bx_hi - bx_lo + 1, rh = by_hi - by_lo + 1;
+            const int npx = (have && rw > 0) ? rw * rh : 0;
             int nmax = 0;                                                                                     // wave-uniform trip count
 #pragma unroll
             for (int g = 0; g < kPerWave; g++) nmax = max(nmax, __builtin_amdgcn_readlane(npx, g * kG));
@@ -391,14 +423,14 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
             const uint32_t m_rw = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(rw, 1))) + 1u;
             for (int p = hl; p < nmax; p += kG) {
                 if (p >= npx) continue;
-                const int dy = (int)(((uint32_t)p * m_rw) >> 16), x = x_lo + (p - dy * rw), y = y_lo + dy;
-                const float px = (float)x, py = (float)y;
+                const int dy = (int)(((uint32_t)p * m_rw) >> 16), lx = bx_lo + (p - dy * rw), ly = by_lo + dy;     // inside the tile
+                const float px = (float)(tx0 + lx), py = (float)(ty0 + ly);
                 const bool border = tile_border && (px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3);      // mesh_core.cpp:211
                 const TriEval ev = eval_texel(t, px, py, border);
                 // `pd > depth_buffer` against the caller's buffer first (also drops NaN); later rivals meet in the LDS maximum
-                const float have_d = FRESH ? kFreshDepth : s_depth[(y - ty0) * kTile + (x - tx0)];
+                const float have_d = FRESH ? kFreshDepth : s_depth[ly * kTile + lx];
                 if (ev.pass && ev.pd > have_d)
-                    atomicMax(&s_key[(y - ty0) * kTile + (x - tx0)], ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~tag);
+                    atomicMax(&s_key[ly * kTile + lx], ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~tag);
             }
         }
     }
@@ -440,51 +472,56 @@ __global__ __launch_bounds__(kBlock) void k_tex_render(const TexP P)
         }
         return;
     }
-    // Four texels per thread, their dependent gathers (triangle -> vertices -> colours) issued level by level for all four:
-    // the chain's latency is paid once per workgroup, not once per texel.
-    int wi[kPer], wv[kPer][3];
-    bool hit[kPer];
+    // Four texels per thread in two halves of two, their dependent gathers (triangle -> vertices -> colours) issued level by level for
+    // both texels of a half: the chain's latency is paid twice per workgroup, not once per texel (all four at once need 52 registers
+    // for the gathered values alone: at this kernel's 64 they spilled, 8.4 M triangles 1.13 -> 1.32 ms).
+    constexpr int kHalf = kPer / 2;
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-        const unsigned long long key = s_key[tid + j * kBlock];
-        hit[j] = key != 0ull;                                      // nobody drew this texel: the caller's background stays
-        wi[j] = hit[j] ? (int)~(uint32_t)key : 0;
-    }
+    for (int h = 0; h < 2; h++) {
+        int wi[kHalf], wv[kHalf][3];
+        bool hit[kHalf];
 #pragma unroll
-    for (int j = 0; j < kPer; j++)
-#pragma unroll
-        for (int m = 0; m < 3; m++) wv[j][m] = hit[j] ? P.triangles[3 * (size_t)wi[j] + m] : 0;
-    float vx[kPer][3], vy[kPer][3], vz[kPer][3];
-#pragma unroll
-    for (int j = 0; j < kPer; j++)
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-            vx[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m]] : 0.f;
-            vy[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m] + 1] : 0.f;
-            vz[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m] + 2] : 0.f;
+        for (int j = 0; j < kHalf; j++) {
+            const unsigned long long key = s_key[tid + (h * kHalf + j) * kBlock];
+            hit[j] = key != 0ull;                                  // nobody drew this texel: the caller's background stays
+            wi[j] = hit[j] ? (int)~(uint32_t)key : 0;
         }
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-        const int e = tid + j * kBlock;
-        const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
-        if (!hit[j]) {
-            if (FRESH && x <= rx_hi && y >= ry_lo && y <= ry_hi) {
-                const size_t o = (size_t)y * P.w + x;
-                for (int k = 0; k < P.c; k++) P.image[o * P.c + k] = P.bg ? P.bg[o * P.c + k] : 0.f;
-                P.depth[o] = kFreshDepth;
+        for (int j = 0; j < kHalf; j++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) wv[j][m] = hit[j] ? P.triangles[3 * (size_t)wi[j] + m] : 0;
+        float vx[kHalf][3], vy[kHalf][3], vz[kHalf][3];
+#pragma unroll
+        for (int j = 0; j < kHalf; j++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                vx[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m]] : 0.f;
+                vy[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m] + 1] : 0.f;
+                vz[j][m] = hit[j] ? P.vertices[3 * (size_t)wv[j][m] + 2] : 0.f;
             }
-            continue;
+#pragma unroll
+        for (int j = 0; j < kHalf; j++) {
+            const int e = tid + (h * kHalf + j) * kBlock;
+            const int x = tx0 + (e & (kTile - 1)), y = ty0 + e / kTile;
+            if (!hit[j]) {
+                if (FRESH && x <= rx_hi && y >= ry_lo && y <= ry_hi) {
+                    const size_t o = (size_t)y * P.w + x;
+                    for (int k = 0; k < P.c; k++) P.image[o * P.c + k] = P.bg ? P.bg[o * P.c + k] : 0.f;
+                    P.depth[o] = kFreshDepth;
+                }
+                continue;
+            }
+            Tri t;
+            setup_from_vertices(vx[j][0], vy[j][0], vx[j][1], vy[j][1], vx[j][2], vy[j][2], vz[j][0], vz[j][1], vz[j][2], t);
+            const float px = (float)x, py = (float)y;
+            const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;
+            const TriEval ev = eval_texel(t, px, py, border);
+            float *out = P.image + ((size_t)y * P.w + x) * P.c;
+            for (int k = 0; k < P.c; k++)
+                out[k] = ev.w0 * P.colors[(size_t)P.c * wv[j][0] + k] + ev.w1 * P.colors[(size_t)P.c * wv[j][1] + k] +
+                         ev.w2 * P.colors[(size_t)P.c * wv[j][2] + k];
+            P.depth[(size_t)y * P.w + x] = ev.pd;
         }
-        Tri t;
-        setup_from_vertices(vx[j][0], vy[j][0], vx[j][1], vy[j][1], vx[j][2], vy[j][2], vz[j][0], vz[j][1], vz[j][2], t);
-        const float px = (float)x, py = (float)y;
-        const bool border = px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3;
-        const TriEval ev = eval_texel(t, px, py, border);
-        float *out = P.image + ((size_t)y * P.w + x) * P.c;
-        for (int k = 0; k < P.c; k++)
-            out[k] = ev.w0 * P.colors[(size_t)P.c * wv[j][0] + k] + ev.w1 * P.colors[(size_t)P.c * wv[j][1] + k] +
-                     ev.w2 * P.colors[(size_t)P.c * wv[j][2] + k];
-        P.depth[(size_t)y * P.w + x] = ev.pd;
     }
 }
 
