@@ -77,7 +77,11 @@ constexpr int kRankSortMax = 512;    // bins up to this length: register-sorted 
 constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
 constexpr int kBuckets = 24;         // tile-length classes (floor(log2 n), descending; last = empty) for launch ordering
 constexpr int kGP = T4D_GRAD_PAIR_FLOATS;
-constexpr int kCursorSegs = 8;       // pair-slot cursors per view (same-address returning atomics are serial: see k_preprocess)
+// pair-slot cursors per view, at most (same-address returning atomics are serial: see k_preprocess).  A view gets one cursor per 16
+// workgroups of Gaussians up to this many: 8 at config 2 (118 workgroups per view), 32 at config 4, 64 for ONE view of 10^6 Gaussians -
+// 3,907 workgroups on 8 cursors were 488 serial atomics each: k_preprocess 60.4 -> 37.8 us there (round 5; 256 cursors: 33.5, but the
+// scan's walk over them costs what that saves)
+constexpr int kCursorSegs = 64;
 // Small launches (the reference's own call shape: ONE view per call, train.py:661-673; a view-sharded rank: three views) cannot
 // fill the chip with whole tiles: a kernel lasts as long as its LONGEST tile list is walked by one workgroup.  For launches of
 // at most kSegMaxTiles tiles the backward is therefore cut along DEPTH: a tile list of n pairs becomes ceil(n / kSeg)

@@ -216,7 +216,7 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
 }
 
 #ifndef T4D_PBWD_WAVES
-#define T4D_PBWD_WAVES 6
+#define T4D_PBWD_WAVES 7         // 72 registers: seven waves per SIMD without a spill (config 2: 32.7 -> 31.3 us; eight spills: 38.0)
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(T4D_PBWD_WAVES, T4D_PBWD_WAVES))) void k_preprocess_bwd(const KP kp)
 {
