@@ -93,7 +93,9 @@ constexpr int kCursorSegs = 64;
 #ifndef T4D_SEG
 #define T4D_SEG 128
 #endif
-constexpr int kSeg = T4D_SEG;        // list positions per backward segment (= kBwdBatch: one staged batch per segment)
+constexpr int kSeg = T4D_SEG;        // list positions per backward segment of a 2-8 view launch; a ONE-view launch takes kSegOne (seg_positions)
+constexpr int kSegOne = 64;          // round 4 measured it with a compile-time switch: one view of Topo4D's size 85.4 -> 81.3 us (half the walk per
+                                     // work item, twice the list rounds in the forward), three views of the config-2 scene 176 -> 183: hence per launch
 constexpr int kSegMaxTiles = 8192;   // launches of at most this many tiles (V * T) run the segmented backward
 constexpr int kSnapFloats = 5;       // T, C0, C1, C2, D per pixel and boundary
 
@@ -135,7 +137,8 @@ inline bool seg_capable(const T4DProblem &p)
 }
 // Segment slots of a view.  Tile t (arena offset off, n pairs) owns the slots floor(off / kSeg) + t ... + ceil(n / kSeg) - 1:
 // disjoint from tile to tile ((off + n) / kSeg - off / kSeg >= floor(n / kSeg)) without a prefix sum over the tiles.
-inline size_t seg_slots_per_view(const T4DProblem &p, size_t T) { return (size_t)p.pair_capacity / kSeg + T + 1; }
+inline int seg_positions(const T4DProblem &p) { return p.n_views == 1 ? kSegOne : kSeg; }
+inline size_t seg_slots_per_view(const T4DProblem &p, size_t T) { return (size_t)p.pair_capacity / (size_t)seg_positions(p) + T + 1; }
 
 Layout make_layout(const T4DProblem &p)
 {
@@ -181,6 +184,7 @@ struct KP {
     float scale_modifier;
     uint32_t cap;
     uint32_t nseg, seg_cap;          // the pair-slot arena of a view is split into nseg segments of seg_cap slots, one cursor each
+    uint32_t seg_shift;              // log2 of the backward's segment length of this launch (seg_positions: 6 or 7)
     const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
     // state
     DevStatus *status;
@@ -580,6 +584,8 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.slot_tab = reinterpret_cast<uint4 *>(st + L.slot_tab);
     kp.snap = reinterpret_cast<float *>(st + L.snap);
     kp.slots_per_view = seg_capable(p) ? (uint32_t)seg_slots_per_view(p, (size_t)kp.T) : 0u;
+    kp.seg_shift = seg_positions(p) == 64 ? 6u : 7u;
+    static_assert(kSegOne == 64 && kSeg == 128, "seg_shift assumes segment lengths of 64 and 128");
 }
 
 }  // namespace
@@ -752,16 +758,20 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     if (getenv("T4D_FILL_SCALAR")) kp.fill_vec = 0u;       // tests: the 4-byte path on images that would take the 16-byte one
     const dim3 fgrid(kp.tile_blocks + kp.fill_blocks);
     const bool seg = kp.slots_per_view != 0u;        // small launch: snapshots for the segmented backward (kSeg)
+    const bool seg_one = seg && seg_positions(p) == kSegOne;
     if (lat) {
-        if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, true, true>), fgrid, dim3(kBlock), 0, stream, kp);
-        else hipLaunchKernelGGL((k_render_fwd<true, kBlock, false, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        if (seg_one) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSegOne, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        else if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSeg, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_fwd<true, kBlock, 0, true>), fgrid, dim3(kBlock), 0, stream, kp);
+    } else if (seg_one) {
+        hipLaunchKernelGGL((k_render_fwd<false, kBlock, kSegOne, true>), fgrid, dim3(kBlock), 0, stream, kp);
     } else if (seg) {
-        hipLaunchKernelGGL((k_render_fwd<false, kBlock, true, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL((k_render_fwd<false, kBlock, kSeg, true>), fgrid, dim3(kBlock), 0, stream, kp);
     } else if (kp.long_bins_elsewhere && getenv("T4D_NO_PRUNE") == nullptr) {
         // a big launch that may hold long lists (the caller has not passed T4D_FLAG_NO_LONG_BINS): a dense pass
-        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, false, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, true>), fgrid, dim3(kBlock), 0, stream, kp);
     } else {
-        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, false, false>), fgrid, dim3(kBlock), 0, stream, kp);
+        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, false>), fgrid, dim3(kBlock), 0, stream, kp);
     }
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
@@ -819,13 +829,15 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
                          : (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 4, 2));
     const uint32_t grid = kp.tile_blocks + (kp.tile_dot ? (uint32_t)p.n_views * ((kp.T + kEmptySpan - 1) / kEmptySpan) : 0u);
 #define T4D_BWD_LAUNCH(DA_, LAT_, SEG_) hipLaunchKernelGGL((k_render_bwd<DA_, LAT_, SEG_>), dim3(grid), dim3(kBlock), 0, stream, kp)
-    if (seg) {
+    if (seg && seg_positions(p) == kSegOne) {
+        if (da) T4D_BWD_LAUNCH(true, false, kSegOne); else T4D_BWD_LAUNCH(false, false, kSegOne);
+    } else if (seg) {
         // Segments always run the throughput build: the latency build's one slab per DPP row is 82 KiB of LDS, ONE workgroup per
         // CU, and a one-view launch has more segments than CUs (432 at Topo4D's size: two rounds, 47 us against 29 us measured)
-        if (da) T4D_BWD_LAUNCH(true, false, true); else T4D_BWD_LAUNCH(false, false, true);
+        if (da) T4D_BWD_LAUNCH(true, false, kSeg); else T4D_BWD_LAUNCH(false, false, kSeg);
     } else {
-        if (lat) { if (da) T4D_BWD_LAUNCH(true, true, false); else T4D_BWD_LAUNCH(false, true, false); }
-        else { if (da) T4D_BWD_LAUNCH(true, false, false); else T4D_BWD_LAUNCH(false, false, false); }
+        if (lat) { if (da) T4D_BWD_LAUNCH(true, true, 0); else T4D_BWD_LAUNCH(false, true, 0); }
+        else { if (da) T4D_BWD_LAUNCH(true, false, 0); else T4D_BWD_LAUNCH(false, false, 0); }
     }
 #undef T4D_BWD_LAUNCH
     }

@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane g
 #ifndef T4D_BWD_DA_WAVES
 #define T4D_BWD_DA_WAVES T4D_BWD_WAVES
 #endif
-#define T4D_BWD_NW (LAT ? 2 : (SEG ? T4D_SEG_WAVES : (DA ? T4D_BWD_DA_WAVES : T4D_BWD_WAVES)))
+#define T4D_BWD_NW (LAT ? 2 : (SEGN != 0 ? T4D_SEG_WAVES : (DA ? T4D_BWD_DA_WAVES : T4D_BWD_WAVES)))
 #define T4D_BWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_BWD_NW, T4D_BWD_NW)))
 constexpr int kAcc = 10;                 // sums per (wave, staged splat) slab entry
 constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the empty-tile share of cotangent_dot
@@ -119,10 +119,14 @@ constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the emp
 // which lets the compiler interleave the four steps of a group.
 // SEG: the segmented backward of small launches (kSeg): a work item is ONE segment of a tile list - workgroup b takes slot b of
 // the slot table - and the replay starts from the forward's snapshot at the segment's far end instead of from the list's end.
-template <bool DA, bool LAT, bool SEG>
+template <bool DA, bool LAT, int SEGN>
 __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
-    static_assert(!SEG || kSeg == kBwdBatch, "one staged batch per segment");
+    constexpr bool SEG = SEGN != 0;
+    // a segment is ONE staged batch: the segmented build stages SEGN splats per round (128, or 64 for a one-view launch), the
+    // whole-tile builds kBwdBatch (these shadow the globals inside the kernel)
+    constexpr int kSeg = SEG ? SEGN : ::kSeg;
+    constexpr int kBwdBatch = SEG ? SEGN : ::kBwdBatch;
     constexpr int kSlabs = LAT ? 16 : 4;
     constexpr int kChunks = (kBwdBatch + 63) / 64;
     constexpr int kListStride = kBwdBatch + 4;

@@ -201,14 +201,17 @@ __device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t
 #define T4D_LAT_WAVES 2          // most waves per SIMD the latency build is compiled for (register budget 512 / this)
 #endif
 #define T4D_FWD_ATTR __attribute__((amdgpu_waves_per_eu(LAT ? 1 : T4D_FWD_WAVES, LAT ? T4D_LAT_WAVES : T4D_FWD_WAVES)))
-// FB: splats staged per batch.  SEG: the launch is small enough for the segmented backward (kSeg): visit lists are built and
-// walked per kSeg list positions, and the blend state at every such boundary is kept for the backward (write_snapshot).
+// FB: splats staged per batch.  SEGN != 0: the launch is small enough for the segmented backward: visit lists are built and walked
+// per SEGN list positions (128, or 64 for a one-view launch: seg_positions), and the blend state at every such boundary is kept for
+// the backward (write_snapshot).
 // PRUNE: finished sub-blocks walk empty lists (below).  A template parameter because its mere presence costs the 72-register
 // build 2.5 % at config 2 (register allocation, not executed instructions: a run-time gate that is never true costs the same),
 // where no list is long enough for it to matter: the host instantiates it for launches that may hold long lists.
-template <bool LAT, int FB, bool SEG, bool PRUNE>
+template <bool LAT, int FB, int SEGN, bool PRUNE>
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
+    constexpr bool SEG = SEGN != 0;
+    constexpr int kSeg = SEG ? SEGN : 128;           // (shadows the global default: this launch's segment length)
     constexpr int kU = LAT ? 8 : 4;                  // steps per group
     // splats staged per batch: the latency build has the LDS of a whole CU and lives as long as its longest tile - fewer batches
     constexpr int kFB = FB;
