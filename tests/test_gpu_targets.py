@@ -49,6 +49,11 @@ def test_label_mask_target_is_the_reference_get_mask_bit_for_bit():
     assert torch.equal(loss.label_mask_target(masks, inner, gts, want_mask=False)[1], tb)
     none, t0 = loss.label_mask_target(masks, np.zeros((0, 3)), gts)          # no label selected: nothing masked
     assert none.sum() == 0 and torch.equal(t0, gts)
+    # the reference's own call shape (helpers.get_mask: label names, cmap_index, per-label colour tiles)
+    cmap_index = {name: i for i, name in enumerate(scene.PARSING_LABELS)}
+    tiles = [torch.tile(torch.tensor(colors[i]).reshape(3, 1, 1), (1, 48, 40)).cuda() for i in range(14)]      # train.py:635
+    got = loss.get_mask(["upper_lip", "inner_mouth", "lower_lip"], torch.tensor(g["mask_image_soft"]).cuda(), cmap_index, tiles)
+    assert np.array_equal(got.cpu().numpy(), g["filtered_mask_soft_3_labels"])
     with pytest.raises(ValueError):
         loss.label_mask_target(masks, np.zeros((17, 3)), gts)
     with pytest.raises(ValueError):

@@ -178,6 +178,15 @@ def label_mask_target(mask_image: torch.Tensor, label_colors, gt: Optional[torch
     return filtered, target
 
 
+def get_mask(target_labels, mask, cmap_index, target_colors) -> torch.Tensor:
+    """Drop-in for helpers.get_mask (helpers.py:811-823), same arguments: `target_labels` label names, `mask` the [3,H,W] label
+    image (colours / 255), `cmap_index` name -> label index (train.py:50-55), `target_colors` the per-label colour tiles
+    (train.py:635: a list of [3,H,W] tensors, one constant colour each - only their first texel is read).  One launch instead of
+    four torch ops per label; returns the same float image of zeros and ones, bit for bit."""
+    colors = [[float(target_colors[cmap_index[label]][c].reshape(-1)[0]) for c in range(3)] for label in target_labels]
+    return label_mask_target(mask, colors, None)[0]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # soft colour (helpers.py:119-120 l1_loss_v2; train.py:407 with weight 0.02, train.py:541-543)
 # ------------------------------------------------------------------------------------------------------------
