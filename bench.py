@@ -11,7 +11,7 @@ One "step" = one pass of the hot path over one batch: forward + backward of the 
 (BASELINE config 2: 24 x 512x512, P = 30,000 vertex-bound Gaussians, precomputed RGB) through the C ABI, with
 all inputs already resident in HBM and seeded dL/dcolor supplied.  One "view" = one
 (Settings, params) -> colour/depth/alpha -> per-view dL/dparams round trip.
-Frames are independent units, so F = 2 of them are in flight on two HIP streams (own state buffers each): the latency-bound
+Frames are independent units, so F = 3 of them (config 4: 2) are in flight on as many HIP streams (own state buffers each): the latency-bound
 binning kernels of one frame run beside the issue-bound render kernels of the other.  Every step is still executed in full, K
 steps are timed; `sequential` in the JSON line is the same run with F = 1, and the per-kernel figures of `roofline` are taken
 with F = 1 (a kernel alone on the chip).
@@ -33,7 +33,10 @@ repeated as often as that takes), `scenario_b` (unsaturated opacities), `single_
 camera per call, P = 8,280, 512x375), `small_v` (1 and 3 views of the config-2 scene per call: a view-sharded rank's launch),
 `forecast` (step time at 24 / 12 / 6 / 3 views => view-sharded strong scaling at 2 / 4 / 8 GPUs), `view_sharded` (the same
 split executed: rank r renders views r::N of every frame), `c4` (BASELINE config 4 with its own roofline), `dense_1m` (one view,
-P = 10^6, 4096x3008), `full_iteration` (render + fused loss + Adam/pins), `drop_in` and `sequential` — see DESIGN.md §Measurement.
+P = 10^6, 4096x3008, and `texture_iteration`: one full iteration of the texture loop, train.py:729-741, at that size), `loss` (the
+fused photometric loss at three shapes with its own roofline), `bake_8192` (BASELINE config 5 with its own roofline and the
+reference's own code timed beside it), `full_iteration` (render + fused loss + Adam/pins), `drop_in` and `sequential` — see
+DESIGN.md §Measurement.
 """
 from __future__ import annotations
 
