@@ -58,16 +58,17 @@ struct TexP {
     int bx, by, by0;              // bins in x, bins in y inside the row band, first bin row of the band
     int n_chunks;
     uint32_t cap;
-    uint32_t *bin_count, *bin_cursor, *bin_off, *chunk_sum, *list;
+    uint32_t *bin_count, *bin_cursor, *bin_off, *chunk_sum;
+    uint4 *list;                  // per (tile, triangle) pair: the triangle's index and its three vertex indices (one fetch level less per tile)
     unsigned long long *total;
     float *image, *depth;
     const float *bg;              // FRESH launches: background image [h,w,c] or nullptr = zeros
 };
 
 // pixel bbox exactly as mesh_core.cpp:190-199, additionally clipped to the row band
-__device__ __forceinline__ bool tri_bbox(const TexP &P, const int i, int &x_min, int &x_max, int &y_min, int &y_max)
+__device__ __forceinline__ bool tri_bbox(const TexP &P, const int i, int &x_min, int &x_max, int &y_min, int &y_max, int &i0, int &i1, int &i2)
 {
-    const int i0 = P.triangles[3 * (size_t)i], i1 = P.triangles[3 * (size_t)i + 1], i2 = P.triangles[3 * (size_t)i + 2];
+    i0 = P.triangles[3 * (size_t)i]; i1 = P.triangles[3 * (size_t)i + 1]; i2 = P.triangles[3 * (size_t)i + 2];
     const float x0 = P.vertices[3 * (size_t)i0], y0 = P.vertices[3 * (size_t)i0 + 1];
     const float x1 = P.vertices[3 * (size_t)i1], y1 = P.vertices[3 * (size_t)i1 + 1];
     const float x2 = P.vertices[3 * (size_t)i2], y2 = P.vertices[3 * (size_t)i2 + 1];
@@ -93,8 +94,9 @@ __global__ __launch_bounds__(kBlock) void k_tex_bin(const TexP P)
     __shared__ uint32_t s_hist[kTexHist], s_hbase[kTexHist];
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = blockIdx.x * kBlock + tid;
-    int x_min, x_max, y_min, y_max;
-    const bool on = i < P.ntri && tri_bbox(P, i, x_min, x_max, y_min, y_max);
+    int x_min, x_max, y_min, y_max, i0 = 0, i1 = 0, i2 = 0;
+    const bool on = i < P.ntri && tri_bbox(P, i, x_min, x_max, y_min, y_max, i0, i1, i2);
+    const uint4 entry = make_uint4((uint32_t)i, (uint32_t)i0, (uint32_t)i1, (uint32_t)i2);
     int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
     if (on) {
         bx0 = x_min / kTile; bx1 = x_max / kTile;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_tex_bin(const TexP P)
             for (int bx = bx0; bx <= bx1; bx++) {
                 const int e = (by - oy) * bw + (bx - ox);
                 const uint32_t pos = s_hbase[e] + atomicAdd(&s_hist[e], 1u);
-                if (pos < P.cap) P.list[pos] = (uint32_t)i;
+                if (pos < P.cap) P.list[pos] = entry;
             }
     } else {
         for (int by = by0; by <= by1; by++)
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_tex_bin(const TexP P)
                 const int b = by * P.bx + bx;
                 if (FILL) {
                     const uint32_t pos = P.bin_off[b] + atomicAdd(&P.bin_cursor[b], 1u);
-                    if (pos < P.cap) P.list[pos] = (uint32_t)i;
+                    if (pos < P.cap) P.list[pos] = entry;
                 } else {
                     atomicAdd(&P.bin_count[b], 1u);
                 }
@@ -269,10 +271,10 @@ __device__ __forceinline__ void setup_from_vertices(const float x0, const float 
     t.d0 = d0; t.d1 = d1; t.d2 = d2;
 }
 
-__device__ __forceinline__ void setup_triangle(const TexP &P, const int i, Tri &t)
+__device__ __forceinline__ void setup_triangle(const TexP &P, const uint4 entry, Tri &t)
 {
 #pragma clang fp contract(off)
-    const int i0 = P.triangles[3 * (size_t)i], i1 = P.triangles[3 * (size_t)i + 1], i2 = P.triangles[3 * (size_t)i + 2];
+    const int i = (int)entry.x, i0 = (int)entry.y, i1 = (int)entry.z, i2 = (int)entry.w;
     const float x0 = P.vertices[3 * (size_t)i0], y0 = P.vertices[3 * (size_t)i0 + 1];
     const float x1 = P.vertices[3 * (size_t)i1], y1 = P.vertices[3 * (size_t)i1 + 1];
     const float x2 = P.vertices[3 * (size_t)i2], y2 = P.vertices[3 * (size_t)i2 + 1];
@@ -289,32 +291,31 @@ __device__ __forceinline__ void setup_triangle(const TexP &P, const int i, Tri &
     t.x_max = min((int)floorf(fmaxf(x0, fmaxf(x1, x2))), P.w - 1);
     t.y_min = max((int)ceilf(fminf(y0, fminf(y1, y2))), 0);
     t.y_max = min((int)floorf(fmaxf(y0, fmaxf(y1, y2))), P.h - 1);
-    t.idx = i; t.i0 = i0; t.i1 = i1;
+    t.idx = i; t.i0 = i0; t.i1 = i1;      // (i2 = entry.w)
 }
 
 // FRESH: the call starts from render.py:72's state - image = background (zeros), depth buffer = -999999 everywhere - which is
 // what `render_colors` always does: the kernel then neither reads the depth buffer nor needs the caller to fill 2 x h x w x 4
 // bytes first; it writes EVERY texel of the band (winner or background).
 // Tiles whose list fits one staging round (<= kStage triangles: every tile of a UV mesh baked at the usual 8 texels per edge)
-// take the fast path: the list is rank-sorted by triangle index, so that a staged record's SLOT orders like its index and the
-// key can carry the slot ("lowest index wins on equal depth" = "lowest slot wins"); the records stay in LDS together with
-// their vertex colours, and the write-out reads the winner's record from LDS instead of gathering triangle -> vertices ->
-// colours per texel (1.0 of the 1.48 ms of the 8192^2 bake in round 2).
+// take the fast path: the records stay in LDS together with their vertex colours, and the key carries the record's staged SLOT
+// below the (inverted) triangle index, so that the write-out reads the winner's record from LDS instead of gathering triangle ->
+// vertices -> colours per texel (1.0 of the 1.48 ms of the 8192^2 bake in round 2).  (Until round 5 the slot WAS the order: the
+// list was rank-sorted by index first - two barriers and an n^2 loop per tile, 0.018 ms of the bake.)
 constexpr float kFreshDepth = -999999.0f;
+constexpr int kSlotBits = 7, kIdxBits = 32 - kSlotBits;   // fast path: key low word = ~index (25 bits) | staged slot (7 bits)
+static_assert(kStage <= (1 << kSlotBits), "a staged slot must fit its bits of the key");
 constexpr int kMaxC = 3;                                 // colour channels the fast path stages (Topo4D: 3; more take the general path)
 
 template <bool FRESH>
-// Eight waves per SIMD (at most 64 registers; it took 78 and ran six): the tile is a chain of dependent fetches - bin header, list,
-// triangles, vertices, colours - and what hides it is other workgroups.  8192^2 bake on one box: 0.618 ms at six, 0.590 at seven, 0.563 at eight.
+// Eight waves per SIMD (at most 64 registers; it took 78 and ran six): the tile is a chain of dependent fetches - bin header, list
+// (which carries the vertex indices: the fill pass has them in registers anyway), vertices | colours - and what hides it is other workgroups.  8192^2 bake on one box: 0.618 ms at six, 0.590 at seven, 0.563 at eight.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 8 : 6, FRESH ? 8 : 6))) void k_tex_render(const TexP P)
 {
 #pragma clang fp contract(off)
     __shared__ TriRec s_tri[kStage];
     __shared__ float s_col[kStage][3][kMaxC];
     __shared__ unsigned long long s_key[kTile * kTile];
-    // the two index arrays of the rank sort live in the keys' memory: the sort is over before the keys are zeroed
-    uint32_t (*s_idx)[kStage] = reinterpret_cast<uint32_t (*)[kStage]>(s_key);
-    static_assert(2 * kStage * sizeof(uint32_t) <= sizeof(unsigned long long) * kTile * kTile, "s_idx must fit into s_key");
     __shared__ float s_depth[FRESH ? 1 : kTile * kTile];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
@@ -353,32 +354,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
         r.idx = t.idx; r.pad = 0;
         return r;
     };
-    const bool fast = n <= (uint32_t)kStage && P.c <= kMaxC && off + n <= P.cap;
-    if (fast) {
-        // ---- rank-sort the list by triangle index (indices are unique inside a bin)
-        if (tid < (int)n) s_idx[0][tid] = P.list[off + tid];
-        __syncthreads();
-        if (tid < (int)n) {
-            const uint32_t mine = s_idx[0][tid];
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < n; q++) rank += s_idx[0][q] < mine ? 1u : 0u;
-            s_idx[1][rank] = mine;
-        }
-        __syncthreads();
-        // ---- records + vertex colours of every triangle of the tile
-        int my_tri = -1;
-        if (tid < (int)n) my_tri = (int)s_idx[1][tid];
-        __syncthreads();                                           // (the index arrays share the keys' memory: done with them)
-        if (my_tri >= 0) {
-            Tri t;
-            setup_triangle(P, my_tri, t);
-            s_tri[tid] = make_rec(t);
-            const int i2 = P.triangles[3 * (size_t)my_tri + 2];
-            for (int k = 0; k < P.c; k++) {
-                s_col[tid][0][k] = P.colors[(size_t)P.c * t.i0 + k];
-                s_col[tid][1][k] = P.colors[(size_t)P.c * t.i1 + k];
-                s_col[tid][2][k] = P.colors[(size_t)P.c * i2 + k];
-            }
+    // One staging round + triangle indices that leave seven bits of the key's low word for the staged slot (below)
+    const bool fast = n <= (uint32_t)kStage && P.c <= kMaxC && off + n <= P.cap && P.ntri <= (1 << kIdxBits);
+    if (fast && tid < (int)n) {
+        // ---- records + vertex colours of every triangle of the tile (in the list's order of arrival)
+        const uint4 entry = P.list[off + tid];
+        Tri t;
+        setup_triangle(P, entry, t);
+        s_tri[tid] = make_rec(t);
+        for (int k = 0; k < P.c; k++) {
+            s_col[tid][0][k] = P.colors[(size_t)P.c * entry.y + k];
+            s_col[tid][1][k] = P.colors[(size_t)P.c * entry.z + k];
+            s_col[tid][2][k] = P.colors[(size_t)P.c * entry.w + k];
         }
     }
     for (int e = tid; e < kTile * kTile; e += kBlock) {           // the caller's depth buffer for this tile: read once, tested from LDS
@@ -395,7 +382,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
             __syncthreads();
             if (tid < cnt) {
                 Tri t;
-                if (off + base + tid < P.cap) setup_triangle(P, (int)P.list[off + base + tid], t);
+                if (off + base + tid < P.cap) setup_triangle(P, P.list[off + base + tid], t);
                 else { memset(&t, 0, sizeof(t)); t.x_min = 1; t.x_max = 0; t.y_min = 1; t.y_max = 0; t.idx = 0x7fffffff; }     // matches no texel
                 s_tri[tid] = make_rec(t);
             }
@@ -417,7 +404,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
             int nmax = 0;                                                                                     // wave-uniform trip count
 #pragma unroll
             for (int g = 0; g < kPerWave; g++) nmax = max(nmax, __builtin_amdgcn_readlane(npx, g * kG));
-            const uint32_t tag = fast ? (uint32_t)k : (uint32_t)t.idx;     // sorted slot or triangle index: lower wins on equal depth
+            // the key's low word: the lower triangle index wins on equal depth (mesh_core.cpp:213 `>` keeps the first); the fast path
+            // appends the staged slot so that the write-out finds the winner's record in LDS without a search
+            const uint32_t low = fast ? ((~(uint32_t)t.idx & ((1u << kIdxBits) - 1u)) << kSlotBits | (uint32_t)k) : ~(uint32_t)t.idx;
             // p / rw without an integer division (~25 instructions per texel, a fifth of this loop): rw <= 32 and p < 1,024, so the
             // 16-bit fixed-point reciprocal m >= 65536 / rw with m rw - 65536 <= rw gives the exact quotient (p (m rw - 65536) < 65536)
             const uint32_t m_rw = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(rw, 1))) + 1u;
@@ -430,7 +419,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
                 // `pd > depth_buffer` against the caller's buffer first (also drops NaN); later rivals meet in the LDS maximum
                 const float have_d = FRESH ? kFreshDepth : s_depth[ly * kTile + lx];
                 if (ev.pass && ev.pd > have_d)
-                    atomicMax(&s_key[ly * kTile + lx], ((unsigned long long)depth_order_bits(ev.pd) << 32) | (uint32_t)~tag);
+                    atomicMax(&s_key[ly * kTile + lx], ((unsigned long long)depth_order_bits(ev.pd) << 32) | low);
             }
         }
     }
@@ -456,7 +445,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
                 }
                 continue;
             }
-            const int slot = (int)~(uint32_t)key;
+            const int slot = (int)((uint32_t)key & ((1u << kSlotBits) - 1u));
             const float px = (float)x, py = (float)y;
             const bool border = tile_border && (px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3);
             const TriEval ev = eval_texel(s_tri[slot], px, py, border);
@@ -540,7 +529,7 @@ TexLayout tex_layout(int h, int w, int64_t cap)
     L.zero_end = o;
     L.bin_off = o;    o = align_up(o + nb * 4);
     L.chunk_sum = o;  o = align_up(o + ((nb + kScanChunk - 1) / kScanChunk) * 4);
-    L.list = o;       o = align_up(o + (size_t)cap * 4);
+    L.list = o;       o = align_up(o + (size_t)cap * sizeof(uint4));
     L.bytes = o;
     return L;
 }
@@ -582,7 +571,7 @@ int texture_bake_impl(const bool fresh, const float *bg, const float *vertices, 
     P.bin_off = (uint32_t *)(sc + L.bin_off);
     P.chunk_sum = (uint32_t *)(sc + L.chunk_sum);
     P.n_chunks = (P.bx * P.by + kScanChunk - 1) / kScanChunk;
-    P.list = (uint32_t *)(sc + L.list);
+    P.list = (uint4 *)(sc + L.list);
     P.image = image; P.depth = depth_buffer; P.bg = bg;
     if (pairs_needed) *pairs_needed = 0;
 #define TEX_HIP(call)                                                                             \
