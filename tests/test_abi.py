@@ -131,7 +131,7 @@ def test_every_compute_export_rejects_bad_arguments_before_touching_a_device():
     assert lib.t4d_adam_step_counters(None, 2) == 0
     # activations, dense interpolation, view sums and dots, visibility
     rejected(lib.t4d_activate_forward(4, one, one, one, one, one, none, none))
-    rejected(lib.t4d_activate_backward(4, one, one, one, one, one, one, one, one, none, none))
+    rejected(lib.t4d_activate_backward(4, one, none, one, one, one, one, one, one, one, none))
     rejected(lib.t4d_activate_forward(-1, one, one, one, one, one, one, none))
     assert lib.t4d_activate_forward(0, none, none, none, none, none, none, none) == _lib.T4D_OK      # nothing to do is not an error
     rejected(lib.t4d_dense_interpolate(one, none, one, one, 4, 4, 3, one, none))

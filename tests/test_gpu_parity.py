@@ -456,6 +456,56 @@ def test_segmented_backward_agrees_with_the_whole_tile_replay(with_depth_alpha, 
             check_grads(res[name][1], g, v)
 
 
+@pytest.mark.parametrize("with_depth_alpha", [False, True])
+def test_long_tiles_of_a_big_one_view_launch_are_segmented(with_depth_alpha, monkeypatch):
+    """The texture pass's call shape - ONE view of more than 8,192 tiles - fills the chip with whole tiles, but a few lists of
+    thousands of pairs would keep their workgroups walking long after the rest has finished: tiles of at least 2,048 pairs are cut
+    into depth segments there (their own launch behind the whole-tile one, which skips them).  A 1472 x 1472 view (8,464 tiles) of a head plus a
+    cluster of 4,000 thin splats over a handful of tiles: against the whole-tile replay of everything (T4D_NO_SEGMENTS) and the C
+    oracle."""
+    H = W = 1472
+    rv, cams = util.make_scene(60, 100, H, W, 1, opacity="B", seed=61)
+    g = torch.Generator().manual_seed(62)
+    n = 4000
+    centre = rv["means3D"][rv["means3D"][:, 2].argmax()]            # the point of the head nearest to camera 0's side
+    extra = {
+        "means3D": centre[None] + torch.randn(n, 3, generator=g) * torch.tensor([0.0015, 0.0015, 0.004]),
+        "colors_precomp": torch.rand(n, 3, generator=g),
+        "rotations": torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1),
+        "opacities": torch.rand(n, 1, generator=g) * 0.03 + 0.005,  # thin: pixels read through a thousand of them
+        "scales": torch.rand(n, 3, generator=g) * 0.0008 + 0.0004,
+    }
+    rv = {k: torch.cat([v, extra[k]]).contiguous() if k in extra else v for k, v in rv.items()}
+    cams = [c._replace(bg=torch.tensor([0.2, 0.1, 0.4])) for c in cams]
+    from scaffold import scene
+    dc, dd, da = scene.output_cotangents(1, H, W, seed=63, depth_alpha=True)
+    if not with_depth_alpha:
+        dd = da = None
+    res = {}
+    for name, noseg in (("whole", "1"), ("hybrid", None)):
+        if noseg:
+            monkeypatch.setenv("T4D_NO_SEGMENTS", noseg)
+        else:
+            monkeypatch.delenv("T4D_NO_SEGMENTS", raising=False)
+        out, gr, batch = util.hip_render(cams, rv, dc, dd, da)
+        res[name] = (out, gr, util.decode_state(batch))
+    st = res["whole"][2]
+    assert ((W + 15) // 16) * ((H + 15) // 16) > 8192
+    assert (st["tile_count"] >= 2048).sum() >= 2                    # some tiles are cut into segments ...
+    assert ((st["tile_count"] > 0) & (st["tile_count"] < 2048)).sum() > 2000       # ... most are not ...
+    assert (st["n_contrib"] > 1024).any()                           # ... and pixels read beyond the eighth boundary of a long one
+    a, b = res["whole"], res["hybrid"]
+    for k in a[0]:
+        np.testing.assert_array_equal(a[0][k], b[0][k])             # (the forward does not look at T4D_NO_SEGMENTS)
+    for k in a[1]:
+        if a[1][k] is not None:
+            scale = np.abs(a[1][k]).max()
+            assert np.abs(a[1][k].astype(np.float64) - b[1][k]).max() <= 2e-5 * scale + 1e-12, k
+    r, go = util.c_oracle_render(cams[0], rv, dc[0], None if dd is None else dd[0], None if da is None else da[0])
+    # (thousands of thin splats over a few pixels: one threshold decision that differs from the oracle's expf moves one splat's gradient)
+    check_grads(b[1], go, 0, max_bad_rows=2)
+
+
 def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
     """Mesh order is what makes the LDS tile histogram of k_preprocess effective; a random permutation at 1024^2 makes
     every workgroup's tile bounding box larger than the histogram, so the per-pair global-atomic fallback runs."""

@@ -236,8 +236,8 @@ T4D_EXPORT int t4d_activate_backward(int64_t P, const float *unnorm_rotations, c
                                      const float *dL_drotations, const float *dL_dopacities, const float *dL_dscales,
                                      float *dL_dunnorm_rotations, float *dL_dlogit_opacities, float *dL_dlog_scales, void *hip_stream)
 {
-    if (P < 0 || (P > 0 && (!unnorm_rotations || !opacities || !scales || !dL_drotations || !dL_dopacities || !dL_dscales ||
-                            !dL_dunnorm_rotations || !dL_dlogit_opacities || !dL_dlog_scales)))
+    // (a NULL cotangent counts as zeros, a NULL output is not wanted: only the forward's inputs / outputs are required)
+    if (P < 0 || (P > 0 && (!unnorm_rotations || !opacities || !scales)))
         return t4d_internal_fail(T4D_ERR_ARG, "t4d_activate_backward: bad arguments%s", "");
     if (P == 0) return T4D_OK;
     hipLaunchKernelGGL(k_activate_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (long long)P,

@@ -97,6 +97,17 @@ constexpr int kSeg = T4D_SEG;        // list positions per backward segment of a
 constexpr int kSegOne = 64;          // round 4 measured it with a compile-time switch: one view of Topo4D's size 85.4 -> 81.3 us (half the walk per
                                      // work item, twice the list rounds in the forward), three views of the config-2 scene 176 -> 183: hence per launch
 constexpr int kSegMaxTiles = 8192;   // launches of at most this many tiles (V * T) run the segmented backward
+// A ONE-view launch of more tiles than that (the texture pass: one 4096 x 3008 view = 48,128 tiles of 10^6 Gaussians) fills the chip
+// with whole tiles - until the short tiles run out and a few workgroups are still walking lists of thousands of pairs: the SAME
+// number of wave-steps (counting build) took the backward 343 us on a scene whose longest list held 1,459 pairs and 400 / 906 us
+// (two cameras) on one with lists of 9,000 - 12,000.  There the tiles of at least kSegLongMin pairs - and only those - are cut into
+// segments (kSeg positions each, their own launch behind the whole-tile one, which skips them): same box, whole tiles / threshold
+// 1,024 / 2,048 / 4,096: 400 / 406 / 403 / 382 us and 906 / 414 / 398 / 529 us.  (Segments for EVERY tile of such a launch, the
+// small launches' way: 488 / 506 us and 50 us more in the forward, which then keeps 40,000 snapshots.)
+#ifndef T4D_SEG_LONG_MIN
+#define T4D_SEG_LONG_MIN 2048
+#endif
+constexpr int kSegLongMin = T4D_SEG_LONG_MIN;
 constexpr int kSnapFloats = 5;       // T, C0, C1, C2, D per pixel and boundary
 
 thread_local char g_err[512] = "";
@@ -130,14 +141,17 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // segmented backward (see kSeg): decided by the problem's dimensions alone, so that t4d_state_bytes, the forward and the
 // backward of a call agree without talking to each other
-inline bool seg_capable(const T4DProblem &p)
+// 0: whole tiles only; 1: every tile is segmented (small launch); 2: the long tiles of a big one-view launch are
+inline int seg_mode(const T4DProblem &p)
 {
     const long long T = (long long)((p.W + T4D_TILE_X - 1) / T4D_TILE_X) * (long long)((p.H + T4D_TILE_Y - 1) / T4D_TILE_Y);
-    return (long long)p.n_views * T <= kSegMaxTiles;
+    if ((long long)p.n_views * T <= kSegMaxTiles) return 1;
+    return p.n_views == 1 ? 2 : 0;
 }
+inline bool seg_capable(const T4DProblem &p) { return seg_mode(p) != 0; }
 // Segment slots of a view.  Tile t (arena offset off, n pairs) owns the slots floor(off / kSeg) + t ... + ceil(n / kSeg) - 1:
 // disjoint from tile to tile ((off + n) / kSeg - off / kSeg >= floor(n / kSeg)) without a prefix sum over the tiles.
-inline int seg_positions(const T4DProblem &p) { return p.n_views == 1 ? kSegOne : kSeg; }
+inline int seg_positions(const T4DProblem &p) { return (p.n_views == 1 && seg_mode(p) == 1) ? kSegOne : kSeg; }
 inline size_t seg_slots_per_view(const T4DProblem &p, size_t T) { return (size_t)p.pair_capacity / (size_t)seg_positions(p) + T + 1; }
 
 Layout make_layout(const T4DProblem &p)
@@ -185,6 +199,8 @@ struct KP {
     uint32_t cap;
     uint32_t nseg, seg_cap;          // the pair-slot arena of a view is split into nseg segments of seg_cap slots, one cursor each
     uint32_t seg_shift;              // log2 of the backward's segment length of this launch (seg_positions: 6 or 7)
+    uint32_t seg_min_pairs;          // tiles of fewer pairs are not segmented (0: every tile is - small launches; kSegLongMin: seg_mode 2)
+    uint32_t seg_skip;               // k_render_bwd, whole-tile build of a seg_mode-2 launch: leave the tiles that own segments to the segmented launch
     const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
     // state
     DevStatus *status;
@@ -585,6 +601,9 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.snap = reinterpret_cast<float *>(st + L.snap);
     kp.slots_per_view = seg_capable(p) ? (uint32_t)seg_slots_per_view(p, (size_t)kp.T) : 0u;
     kp.seg_shift = seg_positions(p) == 64 ? 6u : 7u;
+    // seg_mode 2: the caller's word that no list is long (T4D_FLAG_NO_LONG_BINS) keeps every tile whole
+    kp.seg_min_pairs = seg_mode(p) == 2 ? ((p.flags & T4D_FLAG_NO_LONG_BINS) ? 0xffffffffu : (uint32_t)kSegLongMin) : 0u;
+    kp.seg_skip = 0u;
     static_assert(kSegOne == 64 && kSeg == 128, "seg_shift assumes segment lengths of 64 and 128");
 }
 
@@ -743,7 +762,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         ProfScope ps_(stream, K_SORT_TILES);
         // (1024 threads per bin only pay when some bin is long: with the caller's word that every bin fits the ranking sort, a
         // small launch of several views keeps the 256-thread kernel - 4 views of Topo4D's size: 9.7 against 12.6 us)
-        if (kp.slots_per_view != 0u && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
+        if (seg_mode(p) == 1 && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
             hipLaunchKernelGGL(k_sort_tiles<kLongBlock>, dim3(min(kp.T * p.n_views, 4 * device_cus())), dim3(kLongBlock), 0, stream, kp);
         else
             hipLaunchKernelGGL(k_sort_tiles<kBlock>, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
@@ -757,7 +776,8 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     kp.fill_vec = (p.W % 4 == 0 && (((uintptr_t)io->out_color | (uintptr_t)io->out_depth | (uintptr_t)io->out_alpha) & 15u) == 0) ? 1u : 0u;
     if (getenv("T4D_FILL_SCALAR")) kp.fill_vec = 0u;       // tests: the 4-byte path on images that would take the 16-byte one
     const dim3 fgrid(kp.tile_blocks + kp.fill_blocks);
-    const bool seg = kp.slots_per_view != 0u;        // small launch: snapshots for the segmented backward (kSeg)
+    // small launch, or a big one-view launch that may hold long lists: snapshots for the segmented backward (kSeg)
+    const bool seg = kp.slots_per_view != 0u && kp.seg_min_pairs != 0xffffffffu;
     const bool seg_one = seg && seg_positions(p) == kSegOne;
     if (lat) {
         if (seg_one) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSegOne, true>), fgrid, dim3(kBlock), 0, stream, kp);
@@ -824,12 +844,26 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     const bool lat = latency_launch(kp.T * p.n_views);
     // small launches: one workgroup per segment slot (kSeg; T4D_NO_SEGMENTS=1: whole tiles, for tests and experiments - the
     // forward's state serves both)
-    const bool seg = kp.slots_per_view != 0u && getenv("T4D_NO_SEGMENTS") == nullptr;
+    // (seg_mode 2 - the long tiles of a big one-view launch - only when the caller has not said that there are none: the forward
+    // of a call that says so keeps no snapshots, and a forward that kept them is simply not used)
+    const bool seg_long = seg_mode(p) == 2 && kp.seg_min_pairs != 0xffffffffu && getenv("T4D_NO_SEGMENTS") == nullptr;
+    const bool seg = seg_mode(p) == 1 && getenv("T4D_NO_SEGMENTS") == nullptr;
     kp.tile_blocks = seg ? (uint32_t)p.n_views * kp.slots_per_view
                          : (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 4, 2));
-    const uint32_t grid = kp.tile_blocks + (kp.tile_dot ? (uint32_t)p.n_views * ((kp.T + kEmptySpan - 1) / kEmptySpan) : 0u);
+    uint32_t grid = kp.tile_blocks + (kp.tile_dot ? (uint32_t)p.n_views * ((kp.T + kEmptySpan - 1) / kEmptySpan) : 0u);
 #define T4D_BWD_LAUNCH(DA_, LAT_, SEG_) hipLaunchKernelGGL((k_render_bwd<DA_, LAT_, SEG_>), dim3(grid), dim3(kBlock), 0, stream, kp)
-    if (seg && seg_positions(p) == kSegOne) {
+    if (seg_long) {
+        // two launches: the whole-tile throughput build leaves out the tiles that own segments (the forward wrote their slot-table
+        // entries), then the segmented build walks the slot table with a fixed number of workgroups (most of its cap / kSeg + T
+        // slots are empty: one workgroup per slot would be 79,000 launches for a few thousand segments)
+        kp.seg_skip = 1u;
+        if (da) T4D_BWD_LAUNCH(true, false, 0); else T4D_BWD_LAUNCH(false, false, 0);
+        T4D_LAUNCH_CHECK("k_render_bwd");
+        kp.seg_skip = 0u;
+        kp.tile_blocks = min(kp.slots_per_view, (uint32_t)(8 * device_cus()));
+        grid = kp.tile_blocks;
+        if (da) T4D_BWD_LAUNCH(true, false, kSeg); else T4D_BWD_LAUNCH(false, false, kSeg);
+    } else if (seg && seg_positions(p) == kSegOne) {
         if (da) T4D_BWD_LAUNCH(true, false, kSegOne); else T4D_BWD_LAUNCH(false, false, kSegOne);
     } else if (seg) {
         // Segments always run the throughput build: the latency build's one slab per DPP row is 82 KiB of LDS, ONE workgroup per

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kScanChunk) void k_scan_tiles(const KP kp)
 // segmented backward (kSeg): one slot-table entry per kSeg list positions of a tile, at the slots the tile owns
 __device__ __forceinline__ void write_segment_slots(const KP &kp, const uint32_t id, const uint32_t off, const uint32_t n)
 {
-    if (kp.slots_per_view == 0u || n == 0u) return;
+    if (kp.slots_per_view == 0u || n == 0u || n < kp.seg_min_pairs) return;
     const uint32_t nseg = (n + (1u << kp.seg_shift) - 1u) >> kp.seg_shift;
     uint4 *tab = kp.slot_tab + (size_t)(id >> 20) * kp.slots_per_view + (off >> kp.seg_shift) + (id & 0xfffffu);
     for (uint32_t j = 0; j < nseg; j++) tab[j] = make_uint4(id, off, n, j | 0x80000000u);

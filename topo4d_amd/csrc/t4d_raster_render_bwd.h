@@ -195,18 +195,40 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         return;
     }
     uint4 it;
-    if (SEG) {
-        it = kp.slot_tab[blockIdx.x];                // one slot per workgroup; most slots hold no segment
+    if (SEG && kp.tile_blocks == (uint32_t)kp.V * kp.slots_per_view) {
+        it = kp.slot_tab[blockIdx.x];                // (small launches) one slot per workgroup; most slots hold no segment
         if (it.w == 0u) return;
     }
     for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
-    for (uint32_t item = blockIdx.x; item < (SEG ? blockIdx.x + 1u : (uint32_t)(kp.V * kp.T)); item += kp.tile_blocks) {
-    if (!SEG) it = kp.items[item];
+    // work items: the length-ordered tile list (whole tiles) or the slot table (segments: one slot per workgroup in a small launch, a
+    // strided walk over the mostly empty table of a big one-view launch)
+    const uint32_t n_items = SEG ? (uint32_t)kp.V * kp.slots_per_view : (uint32_t)(kp.V * kp.T);
+    unsigned long long slot_live = 0ull;             // strided walk: which of this workgroup's next 64 slots hold a segment
+    for (uint32_t item = blockIdx.x, round = 0u; item < n_items; item += kp.tile_blocks, round++) {
+    if (SEG) {
+        if (kp.tile_blocks != n_items) {
+            // one gather per 64 slots instead of one dependent scalar load per slot (2,048 workgroups over 79,000 slots: 39 round
+            // trips each, 20-40 us of a launch that has a few thousand segments to do); every wave sees the same mask
+            if ((round & 63u) == 0u) {
+                const uint32_t s_ = item + (uint32_t)lane * kp.tile_blocks;
+                slot_live = __ballot(s_ < n_items && kp.slot_tab[s_].w != 0u);
+            }
+            if (((slot_live >> (round & 63u)) & 1ull) == 0ull) continue;      // workgroup-uniform
+        }
+        it = kp.slot_tab[item];
+        if (it.w == 0u) continue;                    // workgroup-uniform
+    } else {
+        it = kp.items[item];
+    }
     const int seg_j = SEG ? (int)(it.w & 0x7fffffffu) : 0;           // this item's segment: list positions [seg_j kSeg, (seg_j + 1) kSeg)
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
     if (n == 0) break;                                             // ordered by length: only empty tiles remain
+    // a big one-view launch: the tiles the forward cut into segments (it wrote their slot-table entries with their snapshots) are
+    // the segmented launch's
+    if (!SEG && kp.seg_skip != 0u && n >= kp.seg_min_pairs &&
+        kp.slot_tab[(size_t)v * kp.slots_per_view + (off >> kp.seg_shift) + (uint32_t)t_].w != 0u) continue;
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float *r2_in = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
