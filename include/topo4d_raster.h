@@ -65,8 +65,10 @@ enum {
                                   tiles; the two 8-byte words may land one after the other) or by an asynchronous copy
                                   enqueued behind the binning kernels */
     T4D_FLAG_NO_LONG_BINS = 16u,/* forward: the caller knows (T4DStatus.max_tile_pairs of an earlier call on this scene) that no
-                                  tile list exceeds 2048 pairs: the launch of the long-bin sort kernel is skipped.  Only a
-                                  speed hint — longer bins that show up anyway are still sorted correctly, just slowly */
+                                  tile list exceeds 2048 pairs: the launch of the long-bin sort kernel is skipped, and a one-view
+                                  launch of more than 8,192 tiles keeps no snapshots for a depth-segmented backward of its long
+                                  tiles.  Only a speed hint — longer bins that show up anyway are still sorted and replayed
+                                  correctly, just slowly */
     T4D_FLAG_SHORT_BINS = 32u, /* forward: ... and that none exceeds 512 pairs (the one-pass ranking sort): a small launch then
                                   sorts every bin inside the render workgroup of its tile instead of launching a sort kernel.
                                   A speed hint like the one above */
