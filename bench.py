@@ -33,7 +33,8 @@ repeated as often as that takes), `scenario_b` (unsaturated opacities), `single_
 camera per call, P = 8,280, 512x375), `small_v` (1 and 3 views of the config-2 scene per call: a view-sharded rank's launch),
 `forecast` (step time at 24 / 12 / 6 / 3 views => view-sharded strong scaling at 2 / 4 / 8 GPUs), `view_sharded` (the same
 split executed: rank r renders views r::N of every frame), `c4` (BASELINE config 4 with its own roofline), `dense_1m` (one view,
-P = 10^6, 4096x3008, and `texture_iteration`: one full iteration of the texture loop, train.py:729-741, at that size), `loss` (the
+P = 10^6, 4096x3008; `camera_4`: the same from the camera that sees the scene's longest tile lists; `texture_iteration`: one full
+iteration of the texture loop, train.py:729-741, at that size), `loss` (the
 fused photometric loss at three shapes with its own roofline), `bake_8192` (BASELINE config 5 with its own roofline and the
 reference's own code timed beside it), `full_iteration` (render + fused loss + Adam/pins), `drop_in` and `sequential` — see
 DESIGN.md §Measurement.
@@ -578,6 +579,32 @@ def dense_1m_probe(dev, reps=5):
     out = {"workload": "1 view per call, P=1000000, 4096x3008 (WxH), opacity scenario A, forward+backward through the C ABI",
            "ms_per_view": round(min(walls), 3), "ms_runs": [round(x, 3) for x in walls], "views_per_s": round(1e3 / min(walls), 1),
            "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs), "kernels_us": kern}
+    # The same scene from the rig's camera 4, which looks at a polar cap of the lat-long head: hundreds of tiles with lists of
+    # 2,000 - 9,000 pairs (camera 12 above: one of 12,614).  Same wave-steps; what differs is how long the longest tiles keep
+    # their workgroups (their backward is cut into depth segments).
+    try:
+        b4 = ViewBatch(pack_views(scene.camera_rig(H, W, n_views=24, device=dev)[4:5], dev), H, W)
+        f4 = lambda: (b4.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv["colors_precomp"]), b4.backward(dc))
+        saved = topo4d_amd.rasterizer._save_sync_mode()
+        try:
+            topo4d_amd.set_sync_mode("checked")
+            f4()
+            st4 = b4.fetch_status()
+            topo4d_amd.set_sync_mode("lazy")
+            for _ in range(3):
+                f4()
+            torch.cuda.synchronize(dev)
+            _lib.profile_begin()
+            for _ in range(10):
+                f4()
+            torch.cuda.synchronize(dev)
+            k4 = {n: round(1e3 * ms / c, 1) for n, (ms, c) in _lib.profile_end().items() if c}
+        finally:
+            topo4d_amd.rasterizer._restore_sync_mode(saved)
+        out["camera_4"] = {"longest_tile_list": int(st4.max_tile_pairs), "kernels_us": k4, "sum_us": round(sum(k4.values()), 1)}
+        del b4
+    except Exception as e:
+        out["camera_4"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del b, rv, dc
     torch.cuda.empty_cache()
     try:
