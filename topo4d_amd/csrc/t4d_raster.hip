@@ -199,8 +199,6 @@ struct KP {
     uint32_t cap;
     uint32_t nseg, seg_cap;          // the pair-slot arena of a view is split into nseg segments of seg_cap slots, one cursor each
     uint32_t seg_shift;              // log2 of the backward's segment length of this launch (seg_positions: 6 or 7)
-    uint32_t seg_min_pairs;          // tiles of fewer pairs are not segmented (0: every tile is - small launches; kSegLongMin: seg_mode 2)
-    uint32_t seg_skip;               // k_render_bwd, whole-tile build of a seg_mode-2 launch: leave the tiles that own segments to the segmented launch
     const float *views, *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *colors_precomp, *shs;
     // state
     DevStatus *status;
@@ -236,6 +234,8 @@ struct KP {
     uint32_t slots_per_view; // 0: this launch is not segmented
     uint32_t fused_sort;     // k_render_fwd<LAT = true> sorts its tile's bin itself (no k_sort_tiles launch)
     unsigned long long *host_status;  // T4D_FLAG_ASYNC_STATUS on a one-view launch: the caller's pinned 16 bytes, written by the kernel itself
+    // (behind everything else: the kernels of every other launch shape read their arguments from the offsets they always had)
+    uint32_t seg_min_pairs;          // tiles of fewer pairs are not segmented (0: every tile is - small launches; kSegLongMin: seg_mode 2)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -603,7 +603,6 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.seg_shift = seg_positions(p) == 64 ? 6u : 7u;
     // seg_mode 2: the caller's word that no list is long (T4D_FLAG_NO_LONG_BINS) keeps every tile whole
     kp.seg_min_pairs = seg_mode(p) == 2 ? ((p.flags & T4D_FLAG_NO_LONG_BINS) ? 0xffffffffu : (uint32_t)kSegLongMin) : 0u;
-    kp.seg_skip = 0u;
     static_assert(kSegOne == 64 && kSeg == 128, "seg_shift assumes segment lengths of 64 and 128");
 }
 
@@ -856,13 +855,13 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
         // two launches: the whole-tile throughput build leaves out the tiles that own segments (the forward wrote their slot-table
         // entries), then the segmented build walks the slot table with a fixed number of workgroups (most of its cap / kSeg + T
         // slots are empty: one workgroup per slot would be 79,000 launches for a few thousand segments)
-        kp.seg_skip = 1u;
-        if (da) T4D_BWD_LAUNCH(true, false, 0); else T4D_BWD_LAUNCH(false, false, 0);
+        if (da) hipLaunchKernelGGL((k_render_bwd<true, false, 0, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_bwd<false, false, 0, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
         T4D_LAUNCH_CHECK("k_render_bwd");
-        kp.seg_skip = 0u;
         kp.tile_blocks = min(kp.slots_per_view, (uint32_t)(8 * device_cus()));
         grid = kp.tile_blocks;
-        if (da) T4D_BWD_LAUNCH(true, false, kSeg); else T4D_BWD_LAUNCH(false, false, kSeg);
+        if (da) hipLaunchKernelGGL((k_render_bwd<true, false, kSeg, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
+        else hipLaunchKernelGGL((k_render_bwd<false, false, kSeg, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
     } else if (seg && seg_positions(p) == kSegOne) {
         if (da) T4D_BWD_LAUNCH(true, false, kSegOne); else T4D_BWD_LAUNCH(false, false, kSegOne);
     } else if (seg) {

@@ -353,9 +353,13 @@ __global__ __launch_bounds__(kScanChunk) void k_scan_tiles(const KP kp)
 // A.2 scatter keys into tile bins
 // ---------------------------------------------------------------------------------------------------------
 // segmented backward (kSeg): one slot-table entry per kSeg list positions of a tile, at the slots the tile owns
+// BIG: called from a launch that may be a big one-view launch, where only the tiles of at least kp.seg_min_pairs pairs are cut into
+// segments (the one-view kernels of at most 1,024 tiles below never are: they do not even read the field)
+template <bool BIG>
 __device__ __forceinline__ void write_segment_slots(const KP &kp, const uint32_t id, const uint32_t off, const uint32_t n)
 {
-    if (kp.slots_per_view == 0u || n == 0u || n < kp.seg_min_pairs) return;
+    if (kp.slots_per_view == 0u || n == 0u) return;
+    if (BIG && n < kp.seg_min_pairs) return;
     const uint32_t nseg = (n + (1u << kp.seg_shift) - 1u) >> kp.seg_shift;
     uint4 *tab = kp.slot_tab + (size_t)(id >> 20) * kp.slots_per_view + (off >> kp.seg_shift) + (id & 0xfffffu);
     for (uint32_t j = 0; j < nseg; j++) tab[j] = make_uint4(id, off, n, j | 0x80000000u);
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)
         const uint32_t off = kp.tile_off[vt];
         const uint32_t n = off >= kp.cap ? 0u : min(kp.tile_count[vt], kp.cap - off);
         kp.items[b] = make_uint4(id, off, n, kp.tile_count[vt]);       // .w = 0: a truly empty tile (n = 0 also after an arena overflow)
-        write_segment_slots(kp, id, off, n);
+        write_segment_slots<true>(kp, id, off, n);
         return;
     }
     const int v = (int)(blockIdx.x / nb8);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
                 kp.tile_off[t] = off[j];
                 const uint32_t n = off[j] >= kp.cap ? 0u : min(c[j], kp.cap - off[j]);
                 kp.items[s_bpre[bk[j]] + rank[j]] = make_uint4((uint32_t)t, off[j], n, c[j]);       // view 0: id = tile
-                write_segment_slots(kp, (uint32_t)t, off[j], n);
+                write_segment_slots<false>(kp, (uint32_t)t, off[j], n);
             }
         }
         if (tid == 0) {
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void k_front_small(const KP kp)
                 kp.tile_off[t] = off[j];
                 const uint32_t n = off[j] >= kp.cap ? 0u : min(c[j], kp.cap - off[j]);
                 kp.items[s_bpre[bk[j]] + rank[j]] = make_uint4((uint32_t)t, off[j], n, c[j]);       // view 0: id = tile
-                write_segment_slots(kp, (uint32_t)t, off[j], n);
+                write_segment_slots<false>(kp, (uint32_t)t, off[j], n);
             }
         }
         if (tid == 0) {

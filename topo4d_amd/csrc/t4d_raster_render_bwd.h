@@ -119,7 +119,11 @@ constexpr int kEmptySpan = 64;           // tiles per spare workgroup of the emp
 // which lets the compiler interleave the four steps of a group.
 // SEG: the segmented backward of small launches (kSeg): a work item is ONE segment of a tile list - workgroup b takes slot b of
 // the slot table - and the replay starts from the forward's snapshot at the segment's far end instead of from the list's end.
-template <bool DA, bool LAT, int SEGN>
+// LONG: the two launches of a big one-view launch (seg_mode 2) - the whole-tile build (SEGN == 0) leaves out the tiles that own
+// segments, the segmented build (SEGN != 0) walks the mostly empty slot table with a fixed number of workgroups.  A template
+// parameter so that every other launch shape runs the code it always ran (a one-view launch of Topo4D's size lasts 23 us: the same
+// tests at run time in its prologue cost 0.8-1.6 us).
+template <bool DA, bool LAT, int SEGN, bool LONG = false>
 __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 {
     constexpr bool SEG = SEGN != 0;
@@ -195,31 +199,28 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         return;
     }
     uint4 it;
-    if (SEG && kp.tile_blocks == (uint32_t)kp.V * kp.slots_per_view) {
-        it = kp.slot_tab[blockIdx.x];                // (small launches) one slot per workgroup; most slots hold no segment
+    if (SEG && !LONG) {
+        it = kp.slot_tab[blockIdx.x];                // one slot per workgroup; most slots hold no segment
         if (it.w == 0u) return;
     }
     for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
-    // work items: the length-ordered tile list (whole tiles) or the slot table (segments: one slot per workgroup in a small launch, a
-    // strided walk over the mostly empty table of a big one-view launch)
-    const uint32_t n_items = SEG ? (uint32_t)kp.V * kp.slots_per_view : (uint32_t)(kp.V * kp.T);
-    unsigned long long slot_live = 0ull;             // strided walk: which of this workgroup's next 64 slots hold a segment
-    for (uint32_t item = blockIdx.x, round = 0u; item < n_items; item += kp.tile_blocks, round++) {
-    if (SEG) {
-        if (kp.tile_blocks != n_items) {
-            // one gather per 64 slots instead of one dependent scalar load per slot (2,048 workgroups over 79,000 slots: 39 round
-            // trips each, 20-40 us of a launch that has a few thousand segments to do); every wave sees the same mask
-            if ((round & 63u) == 0u) {
-                const uint32_t s_ = item + (uint32_t)lane * kp.tile_blocks;
-                slot_live = __ballot(s_ < n_items && kp.slot_tab[s_].w != 0u);
-            }
-            if (((slot_live >> (round & 63u)) & 1ull) == 0ull) continue;      // workgroup-uniform
+    // work items: the length-ordered tile list (whole tiles), ONE slot of the slot table (segments of a small launch), or a strided
+    // walk over the mostly empty table of a big one-view launch (LONG)
+    unsigned long long slot_live = 0ull;             // LONG: which of this workgroup's next 64 slots hold a segment
+    uint32_t round = 0u;
+    for (uint32_t item = blockIdx.x; item < (SEG ? (LONG ? (uint32_t)kp.V * kp.slots_per_view : blockIdx.x + 1u) : (uint32_t)(kp.V * kp.T)); item += kp.tile_blocks) {
+    if (SEG && LONG) {
+        // one gather per 64 slots instead of one dependent scalar load per slot (2,048 workgroups over 79,000 slots: 39 round
+        // trips each, 20-40 us of a launch that has a few thousand segments to do); every wave sees the same mask
+        const uint32_t r_ = round++;
+        if ((r_ & 63u) == 0u) {
+            const uint32_t s_ = item + (uint32_t)lane * kp.tile_blocks;
+            slot_live = __ballot(s_ < (uint32_t)kp.V * kp.slots_per_view && kp.slot_tab[s_].w != 0u);
         }
+        if (((slot_live >> (r_ & 63u)) & 1ull) == 0ull) continue;      // workgroup-uniform
         it = kp.slot_tab[item];
-        if (it.w == 0u) continue;                    // workgroup-uniform
-    } else {
-        it = kp.items[item];
     }
+    if (!SEG) it = kp.items[item];
     const int seg_j = SEG ? (int)(it.w & 0x7fffffffu) : 0;           // this item's segment: list positions [seg_j kSeg, (seg_j + 1) kSeg)
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     if (n == 0) break;                                             // ordered by length: only empty tiles remain
     // a big one-view launch: the tiles the forward cut into segments (it wrote their slot-table entries with their snapshots) are
     // the segmented launch's
-    if (!SEG && kp.seg_skip != 0u && n >= kp.seg_min_pairs &&
+    if (!SEG && LONG && n >= kp.seg_min_pairs &&
         kp.slot_tab[(size_t)v * kp.slots_per_view + (off >> kp.seg_shift) + (uint32_t)t_].w != 0u) continue;
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float *r2_in = kp.cut_r2 + (size_t)v * kp.cap + off;
