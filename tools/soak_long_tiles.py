@@ -1,0 +1,59 @@
+"""Soak run of the long-tile path of big one-view launches (one view of more than 8,192 tiles: tiles of at least 2,048 pairs are cut
+into depth segments, in a launch of their own behind the whole-tile backward - DESIGN.md section 5 item 1): random heads with
+random clusters of thin splats, the hybrid backward against the whole-tile replay of everything (T4D_NO_SEGMENTS=1; the forward is
+the same program either way and must be bit-equal).  GPU box.
+    python tools/soak_long_tiles.py [first_seed] [n_seeds]      -> one line per failing seed + a summary line."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from scaffold import scene
+from tests import util
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+bad, cut, longest = [], 0, 0
+for seed in range(first, first + n_seeds):
+    rng = np.random.default_rng(seed)
+    H = int(rng.choice([1472, 1536, 2048])); W = int(rng.choice([1472, 1600, 2048]))
+    g = torch.Generator().manual_seed(seed)
+    rv, cams = util.make_scene(int(rng.integers(40, 90)), int(rng.integers(60, 140)), H, W, 1, opacity="B", seed=seed)
+    for _ in range(int(rng.integers(1, 4))):                                   # one to three clusters somewhere on the head
+        n = int(rng.integers(1500, 7000))
+        centre = rv["means3D"][int(rng.integers(0, rv["means3D"].shape[0]))]
+        spread = float(rng.uniform(0.0005, 0.004))
+        extra = {
+            "means3D": centre[None] + torch.randn(n, 3, generator=g) * torch.tensor([spread, spread, 2 * spread]),
+            "colors_precomp": torch.rand(n, 3, generator=g),
+            "rotations": torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1),
+            "opacities": torch.rand(n, 1, generator=g) * float(rng.uniform(0.01, 0.3)) + 0.004,
+            "scales": torch.rand(n, 3, generator=g) * float(rng.uniform(0.0003, 0.002)) + 0.0003,
+        }
+        rv = {k: torch.cat([v, extra[k]]).contiguous() if k in extra else v for k, v in rv.items()}
+    cams = [c._replace(bg=torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)) for c in cams]
+    use_da = bool(seed % 3)
+    dc, dd, da = scene.output_cotangents(1, H, W, seed=seed + 7, depth_alpha=True)
+    if not use_da:
+        dd = da = None
+    try:
+        os.environ["T4D_NO_SEGMENTS"] = "1"
+        o_w, g_w, b_w = util.hip_render(cams, rv, dc, dd, da)
+        os.environ.pop("T4D_NO_SEGMENTS")
+        o_h, g_h, b_h = util.hip_render(cams, rv, dc, dd, da)
+        st = util.decode_state(b_h)
+        cut += int((st["tile_count"] >= 2048).sum()); longest = max(longest, int(st["tile_count"].max()))
+        for k in o_w:
+            assert np.array_equal(o_w[k], o_h[k]), f"forward output {k} differs"
+        for k in g_w:
+            if g_w[k] is None:
+                continue
+            scale = np.abs(g_w[k]).max()
+            err = np.abs(g_w[k].astype(np.float64) - g_h[k]).max()
+            assert err <= 2e-5 * scale + 1e-12, f"grad {k}: {err:.3e} vs scale {scale:.3e}"
+    except Exception as e:
+        os.environ.pop("T4D_NO_SEGMENTS", None)
+        bad.append(seed)
+        print(f"seed {seed} FAILED ({H}x{W}): {str(e).splitlines()[0][:200]}", flush=True)
+print(f"soak long tiles: {n_seeds} scenes (seeds {first}..{first + n_seeds - 1}), {cut} tiles cut into segments, longest list {longest}, "
+      f"{len(bad)} failures {bad[:20]}")
