@@ -503,7 +503,25 @@ def test_long_tiles_of_a_big_one_view_launch_are_segmented(with_depth_alpha, mon
             assert np.abs(a[1][k].astype(np.float64) - b[1][k]).max() <= 2e-5 * scale + 1e-12, k
     r, go = util.c_oracle_render(cams[0], rv, dc[0], None if dd is None else dd[0], None if da is None else da[0])
     # (thousands of thin splats over a few pixels: one threshold decision that differs from the oracle's expf moves one splat's gradient)
+    check_outputs(b[0], r.color, r.depth, r.alpha, 0, max_flips=4)
     check_grads(b[1], go, 0, max_bad_rows=2)
+    # The long tiles' FORWARD runs parallel along depth too (t4d_raster_render_fwd_long.h: segments blended from T = 1, a prefix pass,
+    # the segments in which a pixel stops walked again); T4D_NO_LONG_FWD sends them through the one-pass forward: same decisions but
+    # for pixels within rounding of a threshold, sums associated differently
+    monkeypatch.setenv("T4D_NO_LONG_FWD", "1")
+    o1, g1, b1 = util.hip_render(cams, rv, dc, dd, da)
+    monkeypatch.delenv("T4D_NO_LONG_FWD")
+    s1 = util.decode_state(b1)
+    moved = s1["n_contrib"] != res["hybrid"][2]["n_contrib"]
+    assert moved.sum() <= 4, int(moved.sum())
+    for k in ("color", "depth", "alpha"):
+        err = np.abs(o1[k].astype(np.float64) - b[0][k])
+        assert (err > 5e-6).reshape(err.shape[0], -1, err.shape[-2], err.shape[-1]).any(axis=(0, 1))[~moved[0]].sum() == 0, (k, err.max())
+    assert np.abs(s1["final_T"] - res["hybrid"][2]["final_T"])[~moved].max() <= 1e-6
+    for k in g1:
+        if g1[k] is not None:
+            scale = np.abs(g1[k]).max()
+            assert np.abs(g1[k].astype(np.float64) - b[1][k]).max() <= (2e-5 if moved.sum() == 0 else 2e-2) * scale + 1e-12, k
 
 
 def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():

@@ -1,7 +1,8 @@
 """Soak run of the long-tile path of big one-view launches (one view of more than 8,192 tiles: tiles of at least 2,048 pairs are cut
 into depth segments, in a launch of their own behind the whole-tile backward - DESIGN.md section 5 item 1): random heads with
 random clusters of thin splats, the hybrid backward against the whole-tile replay of everything (T4D_NO_SEGMENTS=1; the forward is
-the same program either way and must be bit-equal).  GPU box.
+the same program either way and must be bit-equal), and the long tiles' depth-parallel forward against the one-pass forward
+(T4D_NO_LONG_FWD=1).  GPU box.
     python tools/soak_long_tiles.py [first_seed] [n_seeds]      -> one line per failing seed + a summary line."""
 import os, sys
 import numpy as np
@@ -13,7 +14,7 @@ from tests import util
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-bad, cut, longest = [], 0, 0
+bad, cut, longest, moved = [], 0, 0, 0
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(seed)
     H = int(rng.choice([1472, 1536, 2048])); W = int(rng.choice([1472, 1600, 2048]))
@@ -51,9 +52,31 @@ for seed in range(first, first + n_seeds):
             scale = np.abs(g_w[k]).max()
             err = np.abs(g_w[k].astype(np.float64) - g_h[k]).max()
             assert err <= 2e-5 * scale + 1e-12, f"grad {k}: {err:.3e} vs scale {scale:.3e}"
+        # the long tiles' depth-parallel FORWARD against the one-pass forward (T4D_NO_LONG_FWD): the same decisions except for pixels
+        # within rounding of a threshold (counted), sums associated differently
+        os.environ["T4D_NO_LONG_FWD"] = "1"
+        o_1, g_1, b_1 = util.hip_render(cams, rv, dc, dd, da)
+        os.environ.pop("T4D_NO_LONG_FWD")
+        s_1 = util.decode_state(b_1)
+        mv = s_1["n_contrib"] != st["n_contrib"]
+        moved += int(mv.sum())
+        assert mv.sum() <= 6, f"{int(mv.sum())} pixels with another last contributor"
+        for k in ("color", "depth", "alpha"):
+            err = np.abs(o_1[k].astype(np.float64) - o_h[k])
+            perpix = err.reshape(err.shape[0], -1, err.shape[-2], err.shape[-1]).max(axis=(0, 1)) if err.ndim == 4 else err.reshape(-1, err.shape[-2], err.shape[-1]).max(axis=0)
+            assert perpix[~mv[0]].max() <= 5e-6, f"forward {k}: {perpix[~mv[0]].max():.3e}"
+            assert err.max() <= 2e-3, f"forward {k} at a moved pixel: {err.max():.3e}"
+        assert np.abs(s_1["final_T"] - st["final_T"])[~mv].max() <= 1e-6, "final_T"
+        for k in g_1:
+            if g_1[k] is None:
+                continue
+            scale = np.abs(g_1[k]).max()
+            err = np.abs(g_1[k].astype(np.float64) - g_h[k]).max()
+            assert err <= (2e-5 if mv.sum() == 0 else 2e-2) * scale + 1e-12, f"grad {k} (one-pass forward): {err:.3e} vs scale {scale:.3e}"
     except Exception as e:
-        os.environ.pop("T4D_NO_SEGMENTS", None)
+        os.environ.pop("T4D_NO_SEGMENTS", None); os.environ.pop("T4D_NO_LONG_FWD", None)
         bad.append(seed)
         print(f"seed {seed} FAILED ({H}x{W}): {str(e).splitlines()[0][:200]}", flush=True)
 print(f"soak long tiles: {n_seeds} scenes (seeds {first}..{first + n_seeds - 1}), {cut} tiles cut into segments, longest list {longest}, "
+      f"{moved} pixels whose last contributor differs between the depth-parallel and the one-pass forward, "
       f"{len(bad)} failures {bad[:20]}")

@@ -108,7 +108,8 @@ constexpr int kSegMaxTiles = 8192;   // launches of at most this many tiles (V *
 #define T4D_SEG_LONG_MIN 2048
 #endif
 constexpr int kSegLongMin = T4D_SEG_LONG_MIN;
-constexpr int kSnapFloats = 5;       // T, C0, C1, C2, D per pixel and boundary
+constexpr int kSnapFloats = 6;       // T, C0, C1, C2, D per pixel and boundary (+ the last contributor so far: the depth-parallel forward of long tiles)
+static_assert((kSegLongMin & (kSegLongMin - 1)) == 0, "k_fwd_long_prefix stops at the first work item of a shorter length CLASS (powers of two)");
 
 thread_local char g_err[512] = "";
 
@@ -444,6 +445,7 @@ __host__ __device__ inline unsigned gaussian_grid(const int P, const int V) { re
 #include "t4d_raster_binning.h"
 #include "t4d_raster_sort.h"
 #include "t4d_raster_render_fwd.h"
+#include "t4d_raster_render_fwd_long.h"
 #include "t4d_raster_render_bwd.h"
 #include "t4d_raster_gaussian_bwd.h"
 
@@ -778,7 +780,20 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // small launch, or a big one-view launch that may hold long lists: snapshots for the segmented backward (kSeg)
     const bool seg = kp.slots_per_view != 0u && kp.seg_min_pairs != 0xffffffffu;
     const bool seg_one = seg && seg_positions(p) == kSegOne;
-    if (lat) {
+    // a big one-view launch that may hold long lists: those tiles go through the depth-parallel kernels (three launches over the
+    // slot table, t4d_raster_render_fwd_long.h); the others through the throughput build, which leaves the long ones out
+    const bool long_fwd = seg && seg_mode(p) == 2 && !lat && getenv("T4D_NO_LONG_FWD") == nullptr;
+    if (long_fwd) {
+        hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, true, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        T4D_LAUNCH_CHECK("k_render_fwd");
+        KP kl = kp;
+        kl.tile_blocks = min(kp.slots_per_view, (uint32_t)(8 * device_cus()));
+        hipLaunchKernelGGL(k_fwd_long_seg<false>, dim3(kl.tile_blocks), dim3(kBlock), 0, stream, kl);
+        T4D_LAUNCH_CHECK("k_fwd_long_seg");
+        hipLaunchKernelGGL(k_fwd_long_prefix, dim3(min((uint32_t)kp.T, (uint32_t)(4 * device_cus()))), dim3(kBlock), 0, stream, kl);
+        T4D_LAUNCH_CHECK("k_fwd_long_prefix");
+        hipLaunchKernelGGL(k_fwd_long_seg<true>, dim3(kl.tile_blocks), dim3(kBlock), 0, stream, kl);
+    } else if (lat) {
         if (seg_one) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSegOne, true>), fgrid, dim3(kBlock), 0, stream, kp);
         else if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSeg, true>), fgrid, dim3(kBlock), 0, stream, kp);
         else hipLaunchKernelGGL((k_render_fwd<true, kBlock, 0, true>), fgrid, dim3(kBlock), 0, stream, kp);

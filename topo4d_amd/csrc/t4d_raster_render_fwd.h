@@ -207,7 +207,9 @@ __device__ __forceinline__ void fill_empty_tile_row(const KP &kp, const uint32_t
 // PRUNE: finished sub-blocks walk empty lists (below).  A template parameter because its mere presence costs the 72-register
 // build 2.5 % at config 2 (register allocation, not executed instructions: a run-time gate that is never true costs the same),
 // where no list is long enough for it to matter: the host instantiates it for launches that may hold long lists.
-template <bool LAT, int FB, int SEGN, bool PRUNE>
+// LONG: a big one-view launch whose long tiles (>= kp.seg_min_pairs pairs) are rendered by the depth-parallel kernels of
+// t4d_raster_render_fwd_long.h: this launch leaves them out.
+template <bool LAT, int FB, int SEGN, bool PRUNE, bool LONG = false>
 __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
 {
     constexpr bool SEG = SEGN != 0;
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
     const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
     const uint32_t off = it.y, n = it.z;
+    if (LONG && n >= kp.seg_min_pairs) continue;     // workgroup-uniform, before anything of this tile is touched
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     float *r2_out = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
