@@ -759,17 +759,21 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // one-pass ranking sort (T4D_FLAG_SHORT_BINS): then the render workgroup of a tile sorts its own bin (no launch at all).
     const bool lat = latency_launch_fwd(kp.T * p.n_views, p.flags);
     kp.fused_sort = (lat && (p.flags & T4D_FLAG_SHORT_BINS) != 0 && getenv("T4D_NO_FUSED_SORT") == nullptr) ? 1u : 0u;
-    if (!kp.fused_sort) {
+    if (!kp.fused_sort || kp.long_bins_elsewhere) {
         ProfScope ps_(stream, K_SORT_TILES);
         // (1024 threads per bin only pay when some bin is long: with the caller's word that every bin fits the ranking sort, a
         // small launch of several views keeps the 256-thread kernel - 4 views of Topo4D's size: 9.7 against 12.6 us)
-        if (seg_mode(p) == 1 && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
+        if (kp.fused_sort) {
+        } else if (seg_mode(p) == 1 && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
             hipLaunchKernelGGL(k_sort_tiles<kLongBlock>, dim3(min(kp.T * p.n_views, 4 * device_cus())), dim3(kLongBlock), 0, stream, kp);
         else
             hipLaunchKernelGGL(k_sort_tiles<kBlock>, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
+        // bins beyond the LDS sort buffer (the caller has not said that there are none): their chunks, then the merges
+        if (kp.long_bins_elsewhere) {
+            hipLaunchKernelGGL(k_sort_long_chunks, dim3(min(kp.T * p.n_views, 2 * device_cus())), dim3(kLongBlock), 0, stream, kp);
+            hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
+        }
     }
-    if (kp.long_bins_elsewhere)
-        hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
     T4D_LAUNCH_CHECK("k_sort_tiles");
     { ProfScope ps_(stream, K_RENDER_FWD);
     kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 6, 2));

@@ -62,7 +62,8 @@ __device__ __forceinline__ uint32_t lower_bound_global(const unsigned long long 
 // registers, then at every level each key finds its slot in the merged pair of runs as (position in its own run) + (keys of
 // the sibling run below it), log2(width)+1 dependent LDS reads; keys wait in registers between the read and the write phase.
 // log2(n/64) levels with two barriers each (a compare-exchange network needs ~60 barriers at this size).
-template <int BLOCK, int CAP>
+// PRE != 0: the keys arrive as sorted runs of PRE (k_sort_long_chunks): only the levels from there on are left.
+template <int BLOCK, int CAP, int PRE = 0>
 __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const uint32_t n, unsigned long long *s_keys,
                                                const int tid, const int wave, const int lane)
 {
@@ -71,11 +72,11 @@ __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const u
     for (uint32_t r = (uint32_t)wave; r < runs; r += BLOCK / 64) {
         const uint32_t i = (r << 6) + (uint32_t)lane;
         unsigned long long k0 = i < n ? keys[i] : ~0ull;           // the last run is padded with +inf
-        wave_sort64(k0, lane);
+        if (PRE == 0) wave_sort64(k0, lane);
         s_keys[i] = k0;
     }
     __syncthreads();
-    for (uint32_t w = 64; w < N; w <<= 1) {
+    for (uint32_t w = PRE != 0 ? (uint32_t)PRE : 64u; w < N; w <<= 1) {
         unsigned long long kk[kPer];
         uint32_t np[kPer];
 #pragma unroll
@@ -106,11 +107,11 @@ __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const u
 // Sort a bin longer than the LDS buffer: chunks of CAP keys are sorted through the LDS, then merged level by level IN GLOBAL
 // MEMORY by the same ranking step, ping-pong between the key arena and the scratch arena of the same size (the bin's keys
 // stay in this XCD's L2).  Four independent binary searches per thread and step overlap their latencies.
-template <int BLOCK, int CAP>
+template <int BLOCK, int CAP, int PRE = 0>
 __device__ __forceinline__ void sort_bin_chunked(unsigned long long *keys, unsigned long long *tmp, const uint32_t n,
                                                  unsigned long long *s_keys, const int tid, const int wave, const int lane)
 {
-    for (uint32_t c = 0; c < n; c += CAP) sort_chunk_lds<BLOCK, CAP>(keys + c, min((uint32_t)CAP, n - c), s_keys, tid, wave, lane);
+    for (uint32_t c = 0; c < n; c += CAP) sort_chunk_lds<BLOCK, CAP, PRE>(keys + c, min((uint32_t)CAP, n - c), s_keys, tid, wave, lane);
     unsigned long long *src = keys, *dst = tmp;
     for (uint32_t w = CAP; w < n; w <<= 1) {
         __threadfence_block();
@@ -234,10 +235,63 @@ __global__ __launch_bounds__(BLOCK) void k_sort_tiles(const KP kp)
     }
 }
 
-// Bins longer than kSortLdsCap keys (dense passes: 191 of 11,544 non-empty bins at P = 1M, 4096x3008, the longest 15,693 keys)
-// get a whole CU each: 1024 threads and 128 KiB of LDS sort up to kLongCap keys without touching memory in between (runs of
-// 64 in registers, then log2(n/64) ranking merges in LDS); even longer bins fall back to LDS-sorted chunks merged in global
-// memory.  Work items are ordered by length class, so the long bins come first and a workgroup stops at the first bin of a shorter class.
+// Bins longer than kSortLdsCap keys (dense passes: 191 of 11,544 non-empty bins at P = 1M, 4096x3008, the longest 15,693 keys).
+// Work items are ordered by length class, so the long bins come first and a workgroup stops at the first bin of a shorter class.
+//   k_sort_long_chunks: every kSortLdsCap-key CHUNK of every long bin is a work unit of its own, sorted through 16 KiB of LDS by
+//     whichever workgroup it falls to (a bin of 12,614 keys: seven units in parallel);
+//   k_sort_long: a whole CU per bin - 1024 threads, 128 KiB of LDS - merges the sorted chunks of up to kLongCap keys without touching
+//     memory in between (ranking merges from runs of kSortLdsCap on: three levels for 16,384 keys); even longer bins are merged in
+//     global memory.
+// (As one kernel - runs of 64 in registers, then log2(n/64) = eight merge levels for the longest bin, by one workgroup - the long
+// bins of a 10^6-Gaussian view took 93 us behind k_sort_tiles' 45: the launch lasted as long as its longest bin.)
+constexpr int kLongScan = 1024;          // long bins a workgroup of k_sort_long_chunks counts in one go
+
+__global__ __launch_bounds__(kLongBlock) void k_sort_long_chunks(const KP kp)
+{
+    __shared__ unsigned long long s_keys[kSortLdsCap];
+    __shared__ uint32_t s_first[kLongScan + 1];          // s_first[i] = units in front of work item i
+    __shared__ uint32_t s_wsum[kLongBlock / 64];
+    static_assert(kLongScan == kLongBlock, "one work item per thread and round");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_items = (uint32_t)(kp.V * kp.T);
+    uint32_t units_before = 0;                           // units of the rounds before this one
+    for (uint32_t base = 0; base < n_items; base += kLongScan) {
+        // chunks of this round's work items (0 for a bin that k_sort_tiles sorts)
+        const uint32_t i = base + (uint32_t)tid;
+        const uint32_t n_i = i < n_items ? kp.items[i].z : 0u;
+        const uint32_t c_i = n_i > (uint32_t)kSortLdsCap ? (n_i + (uint32_t)kSortLdsCap - 1u) / (uint32_t)kSortLdsCap : 0u;
+        const uint32_t incl = wave_incl_scan(c_i);
+        if (lane == 63) s_wsum[wave] = incl;
+        // does the list go on with long bins behind this round?  (ordered by length class: not once a shorter class has begun)
+        const bool more = __syncthreads_or(tid == kLongScan - 1 && n_i >= (uint32_t)kSortLdsCap);
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kLongBlock / 64; w++) {
+            const uint32_t x = s_wsum[w];
+            if (w < wave) woff += x;
+            total += x;
+        }
+        s_first[tid] = woff + incl - c_i;
+        if (tid == 0) s_first[kLongScan] = total;
+        __syncthreads();
+        // this workgroup's units of the round: u = blockIdx.x, + gridDim.x, ... (global unit numbers)
+        for (uint32_t u = blockIdx.x + ((units_before + gridDim.x - 1u - blockIdx.x) / gridDim.x) * gridDim.x; u < units_before + total; u += gridDim.x) {
+            const uint32_t lu = u - units_before;
+            uint32_t pos = 0;                            // the work item that holds local unit lu: the last one with s_first <= lu
+#pragma unroll
+            for (uint32_t st = kLongScan >> 1; st > 0; st >>= 1)
+                if (s_first[pos + st] <= lu) pos += st;
+            const uint4 it = kp.items[base + pos];
+            const uint32_t c = (lu - s_first[pos]) * (uint32_t)kSortLdsCap;
+            unsigned long long *keys = kp.keys + (size_t)(it.x >> 20) * kp.cap + it.y + c;
+            sort_chunk_lds<kLongBlock, kSortLdsCap>(keys, min((uint32_t)kSortLdsCap, it.z - c), s_keys, tid, wave, lane);
+        }
+        units_before += total;
+        if (!more) break;
+        __syncthreads();                                 // (s_first, s_wsum are rewritten by the next round)
+    }
+}
+
 __global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
 {
     __shared__ unsigned long long s_keys[kLongCap];
@@ -252,8 +306,8 @@ __global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
         if (n < (uint32_t)kSortLdsCap) break;
         if (n == (uint32_t)kSortLdsCap) continue;
         unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-        if (n <= (uint32_t)kLongCap) sort_chunk_lds<kLongBlock, kLongCap>(keys, n, s_keys, tid, wave, lane);
-        else sort_bin_chunked<kLongBlock, kLongCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
+        if (n <= (uint32_t)kLongCap) sort_chunk_lds<kLongBlock, kLongCap, kSortLdsCap>(keys, n, s_keys, tid, wave, lane);
+        else sort_bin_chunked<kLongBlock, kLongCap, kSortLdsCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
         __syncthreads();
     }
 }
