@@ -102,6 +102,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         uint32_t last_e = 0xffffffffu;
         if (done_m != ~0ull) {                       // wave-uniform
             // which of the staged splats can touch which of this wave's four sub-blocks (= DPP rows)
+            // (launch 3: a sub-block none of whose pixels stops here walks an empty list - most of them)
+            uint32_t rows_done = 0u;
+            if (FINISH) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) rows_done |= (((done_m >> (16 * r)) & 0xffffull) == 0xffffull ? 1u : 0u) << r;
+            }
             unsigned long long m[4][kChunks];
 #pragma unroll
             for (int c4 = 0; c4 < kChunks; c4++) {
@@ -109,6 +115,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
                 if (lo + ((uint32_t)c4 << 6) < n) {
                     const float4 head = *reinterpret_cast<const float4 *>(s_rec + ((c4 << 6) + lane) * kRec);
                     wave_touch_masks(make_float2(head.x, head.y), head.z, tx, ty, wave, mc);
+                    if (FINISH && rows_done != 0u) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) mc[r] = ((rows_done >> r) & 1u) ? 0ull : mc[r];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; r++) m[r][c4] = mc[r];
@@ -198,30 +208,49 @@ __global__ __launch_bounds__(kBlock) void k_fwd_long_prefix(const KP kp)
         float *slot0 = kp.snap + ((size_t)v * kp.slots_per_view + off / kS + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
         float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
         uint32_t last = 0u, stop_seg = 0xffffffffu;
-        // the next segment's record is requested while this one is multiplied through
-        float r0 = slot0[0], r1 = slot0[kBlock], r2 = slot0[2 * kBlock], r3 = slot0[3 * kBlock], r4 = slot0[4 * kBlock], r5 = slot0[5 * kBlock];
-        for (uint32_t j = 0; j < nb; j++) {
-            float *sp = slot0 + (size_t)j * (kSnapFloats * kBlock);
-            const float q0 = r0, q1 = r1, q2 = r2, q3 = r3, q4 = r4, q5 = r5;
-            if (j + 1u < nb) {
-                const float *sn = sp + kSnapFloats * kBlock;
-                r0 = sn[0]; r1 = sn[kBlock]; r2 = sn[2 * kBlock]; r3 = sn[3 * kBlock]; r4 = sn[4 * kBlock]; r5 = sn[5 * kBlock];
+        // Four segments' records per round, and the NEXT round's requested before this round's are used and overwritten (loads and
+        // stores share one counter on this chip: requested behind the stores, every round waited for its own stores first - a
+        // memory round trip per segment, 26 us for a list of 99).
+        constexpr int kAhead = 4;
+        float qn[kAhead][6];
+        auto request = [&](const uint32_t j0) {
+#pragma unroll
+            for (int a = 0; a < kAhead; a++) {
+                const float *sn = slot0 + (size_t)min(j0 + (uint32_t)a, nb - 1u) * (kSnapFloats * kBlock);
+#pragma unroll
+                for (int f = 0; f < 6; f++) qn[a][f] = sn[f * kBlock];
             }
-            if (stop_seg == 0xffffffffu) {
-                const float t_out = T * fabsf(q0);
-                if (q0 < 0.f || t_out < T4D_T_STOP) {
-                    stop_seg = j;                    // launch 3 walks this segment from the state in the slot before
-                } else {
-                    C0 = fmaf(T, q1, C0); C1 = fmaf(T, q2, C1); C2 = fmaf(T, q3, C2); D = fmaf(T, q4, D);
-                    const uint32_t lc = __float_as_uint(q5);
-                    last = lc != 0u ? lc : last;
-                    T = t_out;
-                    // what the backward reads at the boundary behind this segment (and launch 3 as the state in front of the next)
-                    sp[0] = T; sp[kBlock] = C0; sp[2 * kBlock] = C1; sp[3 * kBlock] = C2; sp[4 * kBlock] = D;
-                    sp[5 * kBlock] = __uint_as_float(last);
+        };
+        request(0u);
+        bool wave_done = false;
+        for (uint32_t j0 = 0; j0 < nb && !wave_done; j0 += kAhead) {
+            float q[kAhead][6];
+#pragma unroll
+            for (int a = 0; a < kAhead; a++)
+#pragma unroll
+                for (int f = 0; f < 6; f++) q[a][f] = qn[a][f];
+            if (j0 + kAhead < nb) request(j0 + kAhead);
+#pragma unroll
+            for (int a = 0; a < kAhead; a++) {
+                const uint32_t j = j0 + (uint32_t)a;
+                if (j >= nb) break;                  // workgroup-uniform
+                float *sp = slot0 + (size_t)j * (kSnapFloats * kBlock);
+                if (stop_seg == 0xffffffffu) {
+                    const float t_out = T * fabsf(q[a][0]);
+                    if (q[a][0] < 0.f || t_out < T4D_T_STOP) {
+                        stop_seg = j;                // launch 3 walks this segment from the state in the slot before
+                    } else {
+                        C0 = fmaf(T, q[a][1], C0); C1 = fmaf(T, q[a][2], C1); C2 = fmaf(T, q[a][3], C2); D = fmaf(T, q[a][4], D);
+                        const uint32_t lc = __float_as_uint(q[a][5]);
+                        last = lc != 0u ? lc : last;
+                        T = t_out;
+                        // what the backward reads at the boundary behind this segment (and launch 3 as the state in front of the next)
+                        sp[0] = T; sp[kBlock] = C0; sp[2 * kBlock] = C1; sp[3 * kBlock] = C2; sp[4 * kBlock] = D;
+                        sp[5 * kBlock] = __uint_as_float(last);
+                    }
                 }
             }
-            if (__ballot(stop_seg == 0xffffffffu) == 0ull) break;           // the wave's pixels have all found their segment
+            wave_done = __ballot(stop_seg == 0xffffffffu) == 0ull;          // the wave's pixels have all found their segment
         }
         if (!inside) continue;
         if (stop_seg != 0xffffffffu) {
