@@ -522,6 +522,24 @@ def test_long_tiles_of_a_big_one_view_launch_are_segmented(with_depth_alpha, mon
         if g1[k] is not None:
             scale = np.abs(g1[k]).max()
             assert np.abs(g1[k].astype(np.float64) - b[1][k]).max() <= (2e-5 if moved.sum() == 0 else 2e-2) * scale + 1e-12, k
+    # <outputs, cotangents> from the replay: the long tiles' share comes from their first segments, the others' from the whole-tile launch
+    from topo4d_amd import ViewBatch, pack_views
+    dev = torch.device("cuda")
+    batch = ViewBatch(pack_views(util.to_device(cams, dev), dev), H, W, 1.0, 0)
+    d = lambda k: rv[k].to(dev)
+    color, _, depth, alpha = batch.forward(d("means3D"), d("opacities"), d("scales"), d("rotations"), d("colors_precomp"))
+    cot = [t if t is None else t.to(dev) for t in (dc, dd, da)]
+    dot = torch.full((1,), float("nan"), device=dev)
+    g_with = batch.backward(*cot, cotangent_dot=dot)
+    want = (color.double() * cot[0].double()).sum()
+    scale = (color.double() * cot[0].double()).abs().sum()
+    if with_depth_alpha:
+        want = want + (depth.double() * cot[1].double()).sum() + (alpha.double() * cot[2].double()).sum()
+        scale = scale + (depth.double() * cot[1].double()).abs().sum() + (alpha.double() * cot[2].double()).abs().sum()
+    assert abs(float(dot[0]) - float(want)) <= 2e-6 * float(scale), (dot, want, scale)
+    for k in g_with:
+        if g_with[k] is not None:
+            assert np.array_equal(g_with[k].cpu().numpy().reshape(b[1][k].shape), b[1][k]), k
 
 
 def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
