@@ -398,3 +398,16 @@ def test_texture_iteration_at_the_texture_pass_size():
     for k in pe:
         assert torch.equal(pe[k], pa[k]), (k, (pe[k] - pa[k]).abs().max())
     assert (pe['dense_rgb_colors'][frozen] != 0).any() and (pe['dense_rgb_colors'][~frozen] != p['rgb_colors'].cuda()[~frozen]).any()
+    # ... and replayed from a HIP graph (the forward of this launch is five kernels since its long tiles are rendered parallel along
+    # depth, the backward two: all of them must be capturable): the same parameters after the same two iterations
+    params = {"dense_" + k: torch.nn.Parameter(v.clone().cuda()) for k, v in p.items()}
+    params['dense_means3D'].requires_grad_(False)
+    variables = {'dense_init_colors': params['dense_rgb_colors'].detach().clone()}
+    opt = FusedAdamPins(_groups(params, lrs), eps=1e-15, capturable=True)
+    opt.set_pin('dense_rgb_colors', frozen, 0.0)
+    gv = loop.GraphedViews(params, dataset, opt, dense=True, variables=variables)
+    lg = [gv.step(0).clone() for _ in range(2)]
+    gv.check()
+    assert torch.equal(torch.stack(lg), le)
+    for k in pe:
+        assert torch.equal(params[k].detach(), pe[k]), (k, (params[k].detach() - pe[k]).abs().max())
