@@ -17,7 +17,7 @@ n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 bad, cut, longest, moved = [], 0, 0, 0
 for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(seed)
-    H = int(rng.choice([1472, 1536, 2048])); W = int(rng.choice([1472, 1600, 2048]))
+    H = int(rng.choice([1472, 1475, 1536, 2044, 2048])); W = int(rng.choice([1472, 1480, 1600, 2041, 2048]))      # (ragged sizes too: partial tiles on the right and bottom edges)
     g = torch.Generator().manual_seed(seed)
     rv, cams = util.make_scene(int(rng.integers(40, 90)), int(rng.integers(60, 140)), H, W, 1, opacity="B", seed=seed)
     for _ in range(int(rng.integers(1, 4))):                                   # one to three clusters somewhere on the head
