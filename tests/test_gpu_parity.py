@@ -522,6 +522,13 @@ def test_long_tiles_of_a_big_one_view_launch_are_segmented(with_depth_alpha, mon
         if g1[k] is not None:
             scale = np.abs(g1[k]).max()
             assert np.abs(g1[k].astype(np.float64) - b[1][k]).max() <= (2e-5 if moved.sum() == 0 else 2e-2) * scale + 1e-12, k
+    # `debug=True` of the settings tuple (synchronise + check after every kernel - eight more launches than a small view has): same bits
+    o_d, g_d, _ = util.hip_render([c._replace(debug=True) for c in cams], rv, dc, dd, da)
+    for k in b[0]:
+        np.testing.assert_array_equal(o_d[k], b[0][k])
+    for k in g_d:
+        if g_d[k] is not None:
+            np.testing.assert_array_equal(g_d[k], b[1][k])
     # <outputs, cotangents> from the replay: the long tiles' share comes from their first segments, the others' from the whole-tile launch
     from topo4d_amd import ViewBatch, pack_views
     dev = torch.device("cuda")
