@@ -549,6 +549,45 @@ def test_long_tiles_of_a_big_one_view_launch_are_segmented(with_depth_alpha, mon
             assert np.array_equal(g_with[k].cpu().numpy().reshape(b[1][k].shape), b[1][k]), k
 
 
+def test_long_tiles_with_sh_colours(monkeypatch):
+    """The long tiles' kernels read the colours the SH evaluation of k_preprocess left behind (per view), not `colors_precomp`: a
+    1472 x 1472 view with SH degree 1 and a cluster of thin splats, against the C oracle, the one-pass forward and the whole-tile replay."""
+    H = W = 1472
+    rv, cams = util.make_scene(50, 80, H, W, 1, opacity="B", sh_degree=1, seed=81)
+    g = torch.Generator().manual_seed(82)
+    n = 4000
+    centre = rv["means3D"][rv["means3D"][:, 2].argmax()]
+    extra = {
+        "means3D": centre[None] + torch.randn(n, 3, generator=g) * torch.tensor([0.0015, 0.0015, 0.004]),
+        "shs": torch.randn(n, rv["shs"].shape[1], 3, generator=g) * 0.3,
+        "rotations": torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1),
+        "opacities": torch.rand(n, 1, generator=g) * 0.03 + 0.005,
+        "scales": torch.rand(n, 3, generator=g) * 0.0008 + 0.0004,
+    }
+    rv = {k: torch.cat([v, extra[k]]).contiguous() if k in extra else v for k, v in rv.items()}
+    from scaffold import scene
+    dc, dd, da = scene.output_cotangents(1, H, W, seed=83, depth_alpha=True)
+    keys = ("means3D", "means2D", "opacities", "scales", "rotations", "shs")
+    out, gr, batch = util.hip_render(cams, rv, dc, dd, da)
+    st = util.decode_state(batch)
+    assert (st["tile_count"] >= 2048).sum() >= 2
+    r, go = util.c_oracle_render(cams[0], rv, dc[0], dd[0], da[0])
+    check_outputs(out, r.color, r.depth, r.alpha, 0, max_flips=4)
+    check_grads(gr, go, 0, keys=keys, max_bad_rows=2)
+    for env in ("T4D_NO_LONG_FWD", "T4D_NO_SEGMENTS"):
+        monkeypatch.setenv(env, "1")
+        o1, g1, b1 = util.hip_render(cams, rv, dc, dd, da)
+        monkeypatch.delenv(env)
+        moved = util.decode_state(b1)["n_contrib"] != st["n_contrib"]
+        assert moved.sum() <= 4
+        for k in ("color", "depth", "alpha"):
+            err = np.abs(o1[k].astype(np.float64) - out[k])
+            assert (err > 5e-6).reshape(err.shape[0], -1, H, W).any(axis=(0, 1))[~moved[0]].sum() == 0, (env, k, err.max())
+        for k in keys:
+            scale = np.abs(g1[k]).max()
+            assert np.abs(g1[k].astype(np.float64) - gr[k]).max() <= (2e-5 if moved.sum() == 0 else 2e-2) * scale + 1e-12, (env, k)
+
+
 def test_shuffled_gaussian_order_takes_the_global_atomic_binning_path():
     """Mesh order is what makes the LDS tile histogram of k_preprocess effective; a random permutation at 1024^2 makes
     every workgroup's tile bounding box larger than the histogram, so the per-pair global-atomic fallback runs."""
