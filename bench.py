@@ -154,7 +154,7 @@ class Workload:
     latency-bound binning kernels of one frame run beside the issue-bound render kernels of the other."""
 
     def __init__(self, cfgname, opacity, dev, rank=0, world=1, in_flight=2, n_frames=64, resident=8, gather=None,
-                 view_shard=None, allreduce_grads=False, n_views=None):
+                 view_shard=None, allreduce_grads=False, n_views=None, frames_per_launch=1):
         from scaffold import reference_boundary as boundary, scene
         from topo4d_amd import ViewBatch, dist as t4d_dist, pack_views
         self.t4d_dist = t4d_dist
@@ -185,19 +185,26 @@ class Workload:
         cams = [cams[i] for i in mine]
         dc = dc[mine]
         self.V = V = len(mine)
+        # frames_per_launch = G > 1: ONE launch set carries this workload's views of G consecutive frames, each frame with its own
+        # Gaussians (T4DProblem.views_per_param_set).  The frames of config 3's synthetic sequence are independent units,
+        # so a view-sharded rank - 3 cameras per frame - launches 3 x 8 views at the efficiency of a 24-view launch.  A step is then G frames.
+        self.G = G = max(1, int(frames_per_launch))
         views = pack_views(cams, dev)
+        if G > 1:
+            views = views.repeat(G, 1)
+            dc = dc.repeat(G, 1, 1, 1)
         self.dc = dc.to(dev).contiguous()
         # T4D_BENCH_DA=1 (experiments; never the default): depth and alpha cotangents too - the backward's DA = true instantiation
         # (Topo4D discards depth and alpha, train.py:307: its backward never runs it)
         self.dd = self.da = None
         if os.environ.get("T4D_BENCH_DA") == "1":
             _, dd, da = scene.output_cotangents(self.full_views, H, W, seed=0, depth_alpha=True)
-            self.dd, self.da = dd[mine].to(dev).contiguous(), da[mine].to(dev).contiguous()
+            self.dd, self.da = dd[mine].repeat(G, 1, 1, 1).to(dev).contiguous(), da[mine].repeat(G, 1, 1, 1).to(dev).contiguous()
         # per-frame Gaussians of the synthetic 64-frame sequence (config 3); all resident in HBM before timing
         self.n_frames = n_frames
         my_frames = t4d_dist.shard_units(n_frames, rank, world) if view_shard is None else list(range(n_frames))
         self.rv_frames = []
-        for t in my_frames[: max(1, min(len(my_frames), resident))]:
+        for t in my_frames[: max(1, min(len(my_frames), resident * G))]:
             p = dict(params)
             p["means3D"] = scene.frame_displacement(base_means, t, n_frames)
             rv = {k: v.detach().to(dev) for k, v in boundary.params2rendervar(p).items()}
@@ -205,9 +212,16 @@ class Workload:
                 rv["shs"] = params["shs"].to(dev)
                 rv.pop("colors_precomp")
             self.rv_frames.append(rv)
+        if G > 1:
+            # groups of G consecutive frames, every per-Gaussian input stacked [G, P, .] (the last group wraps around)
+            fr = self.rv_frames
+            n_groups = max(1, len(fr) // G)
+            self.rv_frames = [{k: torch.stack([fr[(j * G + i) % len(fr)][k] for i in range(G)], 0).contiguous() for k in fr[0]}
+                              for j in range(n_groups)]
         self.F = F = max(1, in_flight)
-        # one slot per frame in flight: its own state buffers (ViewBatch), stream, loss and gather buffers
-        self.batches = [ViewBatch(views.contiguous(), H, W, 1.0, cfg["sh_degree"] or 0) for _ in range(F)]
+        V = self.V * G                    # views per launch set
+        # one slot per launch set in flight: its own state buffers (ViewBatch), stream, loss and gather buffers
+        self.batches = [ViewBatch(views.contiguous(), H, W, 1.0, cfg["sh_degree"] or 0, param_sets=G) for _ in range(F)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [None]
         # multi-GPU: the loss all_gather of a step overlaps with the following steps; a slot waits for its previous gather
         # before it rewrites its buffers (F = 1: two buffer sets, the gather of step i is waited on at step i + 2)
@@ -494,21 +508,37 @@ def small_v_probe(dev):
 
 
 def forecast_probe(dev, in_flight):
-    """What view sharding (BASELINE config 3: 'views sharded across 8 MI355X') would give, measured on ONE GPU: the step time of
-    24 / 12 / 6 / 3 views of the config-2 scene per launch = what one rank of a 1 / 2 / 4 / 8-way view shard runs per frame.
-    Frames of Topo4D's real loop are sequential (train.py:646), so ONE frame is in flight here; predicted strong-scaling speed-up
-    at N GPUs = t(24) / t(24 / N) (no collective cost included: the loss gather is 24 floats)."""
-    out = {"workload": "config-2 scene, V views per launch, one frame at a time (frames of the real loop are sequential)", "steps": 50}
+    """What view sharding (BASELINE config 3: 'views sharded across 8 MI355X') gives, measured on ONE GPU: what one rank of a
+    1 / 2 / 4 / 8-way view shard runs - its 24 / 12 / 6 / 3 cameras of N consecutive frames per launch set (the frames of the
+    64-frame synthetic sequence are independent: each carries its own Gaussians, T4DProblem.views_per_param_set), `in_flight` sets
+    in flight.  Predicted strong-scaling speed-up at N GPUs = N * t_set(1) / t_set(N): the job's 64 frames are 64 / N launch
+    sets per rank (no collective cost included: the loss gather is 24 floats per frame).
+    `sequential_frames`: the same split with ONE frame per launch on one stream - the schedule Topo4D's real loop allows, whose
+    frames are sequential (train.py:646): speed-up = t(24 views) / t(24 / N views)."""
+    sync = lambda: torch.cuda.synchronize(dev)
+    out = {"workload": f"config-2 scene; rank 0 of an N-way view shard: 24 / N cameras x N frames per launch set, {in_flight} sets in flight", "steps": 24}
     t = {}
+    for n in (1, 2, 4, 8):
+        wl = Workload("C2", "A", dev, in_flight=in_flight, n_views=24 // n, resident=2, frames_per_launch=n)
+        wl.learn_capacity()
+        dt, _, st = timed_run(wl, 24, 3, 0.05, sync, lambda x: x, regions=5, min_region_s=0.05)
+        t[n] = dt / 24
+        out[f"ms_per_launch_set_n{n}"] = st["ms_per_step"]["median"]
+        del wl
+    out["predicted_view_sharded_speedup"] = {str(n): round(n * t[1] / t[n], 2) for n in (2, 4, 8)}
+    out["predicted_views_per_s"] = {str(n): round(24 * n / t[n], 1) for n in (1, 2, 4, 8)}
+    seq = {"workload": "V views of ONE frame per launch, one frame at a time on one stream", "steps": 50}
+    ts = {}
     for v in (24, 12, 6, 3):
         wl = Workload("C2", "A", dev, in_flight=1, n_views=v, resident=2)
         wl.learn_capacity()
-        dt, _, st = timed_run(wl, 50, 3, 0.05, lambda: torch.cuda.synchronize(dev), lambda x: x, regions=5, min_region_s=0.05)
-        t[v] = dt / 50
-        out[f"ms_per_step_v{v}"] = st["ms_per_step"]["median"]
+        dt, _, st = timed_run(wl, 50, 3, 0.05, sync, lambda x: x, regions=5, min_region_s=0.05)
+        ts[v] = dt / 50
+        seq[f"ms_per_step_v{v}"] = st["ms_per_step"]["median"]
         del wl
-    out["predicted_view_sharded_speedup"] = {str(n): round(t[24] / t[24 // n], 2) for n in (2, 4, 8)}
-    out["predicted_views_per_s"] = {str(n): round(24 / t[24 // n], 1) for n in (1, 2, 4, 8)}
+    seq["predicted_view_sharded_speedup"] = {str(n): round(ts[24] / ts[24 // n], 2) for n in (2, 4, 8)}
+    seq["predicted_views_per_s"] = {str(n): round(24 / ts[24 // n], 1) for n in (1, 2, 4, 8)}
+    out["sequential_frames"] = seq
     return out
 
 
@@ -849,6 +879,11 @@ def main():
     ap.add_argument("--shard", default="frames", choices=["frames", "views"],
                     help="frames: rank r renders frames r, r+N, ... (24 views each); views: every rank steps through all frames and "
                          "renders views r::N of each (strong scaling of ONE frame: the split Topo4D's sequential frames allow)")
+    ap.add_argument("--frames-per-launch", dest="frames_per_launch", type=int, default=0,
+                    help="--shard views: independent frames whose views one launch set carries, each frame with its own Gaussians "
+                         "(T4DProblem.views_per_param_set).  Default: N, the number of ranks - every launch set holds 24 views like the "
+                         "one-GPU run's, --frames-in-flight of them in flight.  1: one frame at a time on one stream - the schedule of "
+                         "Topo4D's real loop, whose frames are sequential (train.py:646)")
     ap.add_argument("--allreduce-grads", action="store_true", help="--shard views: sum the view-summed parameter gradients over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the scenario-B and single-view side measurements")
@@ -902,20 +937,27 @@ def main():
         # round 3, same box; `sequential` in the JSON line is the same steps one frame at a time
         args.in_flight = 3 if args.config == "C2" else 2
     by_views = args.shard == "views"
+    G = 1
     if by_views:
-        # one frame is in flight: the frames of the loop this split serves are sequential (train.py:646)
-        args.scaling, args.in_flight = "strong", 1
+        args.scaling = "strong"
         shard = (rank, world)
         if world == 1 and os.environ.get("T4D_BENCH_VIEW_SHARD"):     # tests: ONE process renders rank r's shard of an N-way split ("r/N")
             shard = tuple(int(x) for x in os.environ["T4D_BENCH_VIEW_SHARD"].split("/"))
-        wl = Workload(args.config, args.opacity, dev, rank, world, 1, gather=dist is not None, view_shard=shard,
-                      allreduce_grads=args.allreduce_grads)
+        # The 64 frames of config 3's synthetic sequence are independent units: a rank's launch set carries its 24 / N cameras of
+        # N consecutive frames (24 views, like the one-GPU run's launch sets), several such sets in flight.  --frames-per-launch 1 is
+        # the schedule Topo4D's real loop allows (its frames are sequential, train.py:646): one frame, one stream.
+        G = args.frames_per_launch if args.frames_per_launch > 0 else shard[1]
+        if G == 1:
+            args.in_flight = 1
+        wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None, view_shard=shard,
+                      allreduce_grads=args.allreduce_grads, frames_per_launch=G)
     else:
         wl = Workload(args.config, args.opacity, dev, rank, world, args.in_flight, gather=dist is not None)
     cfg, H, W, V, P = wl.cfg, wl.H, wl.W, wl.V, wl.P
-    my_steps = args.steps if by_views else (strong_steps_per_rank if args.scaling == "strong" else args.steps)
-    # views per step over ALL ranks: a view-sharded step is one whole frame; a frame-sharded step is one frame per rank
-    views_per_step_job = wl.full_views if by_views else V * world
+    # a view-sharded step is one launch set = G whole frames (--steps counts FRAMES there, rounded up to whole launch sets)
+    my_steps = -(-args.steps // G) if by_views else (strong_steps_per_rank if args.scaling == "strong" else args.steps)
+    # views per step over ALL ranks: a view-sharded step is G whole frames; a frame-sharded step is one frame per rank
+    views_per_step_job = wl.full_views * G if by_views else V * world
 
     def barrier():
         wl.drain()
@@ -981,16 +1023,17 @@ def main():
     prof, tp = kernel_profile(wl, my_steps)
     roofline = None
     sh_bytes = 0 if cfg["sh_degree"] is None else 3 * (cfg["sh_degree"] + 1) ** 2 * 4
-    R_view = total_pairs_all / V
+    VL = V * G                       # views per launch set
+    R_view = total_pairs_all / VL
     per_kernel, total_bytes = algorithmic_bytes(P, R_view, H * W, sh_bytes)
     if rank == 0:
         kernels = {}
         for name, (ms, n) in prof.items():
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": n,
-                                 "alg_GBs": round(per_kernel[name] * V / (1e-3 * ms / n) / 1e9, 1)}
+                                 "alg_GBs": round(per_kernel[name] * VL / (1e-3 * ms / n) / 1e9, 1)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
-        ach = per_kernel[dom] * V / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+        ach = per_kernel[dom] * VL / (kernels[dom]["avg_us"] * 1e-6) / 1e9
         traffic = load_profile_json("traffic.json", args.config, dom)
         # vector-ALU counters of the committed rocprofv3 --pmc passes (tools/prof.sh -> profiles/valu.json): what actually limits
         # the render kernels.  busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * kernel cycles).
@@ -1008,7 +1051,7 @@ def main():
         roofline = {"bound": ("valu" if busy is not None and busy > 0.6 else "hbm"), "kernel": dom, "achieved": round(ach, 1),
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                    "alg_bytes_per_launch": int(per_kernel[dom] * V), "avg_us": kernels[dom]["avg_us"],
+                    "alg_bytes_per_launch": int(per_kernel[dom] * VL), "avg_us": kernels[dom]["avg_us"],
                     "pairs_per_view": int(R_view), "ms_per_step_profiled": round(1e3 * tp / my_steps, 4),
                     "pipeline_alg_bytes_per_view": int(total_bytes), "kernels": kernels,
                     "valu": valu, "issue": issue,
@@ -1018,23 +1061,38 @@ def main():
     if dist is not None:
         barrier()
 
-    # ---- the view-sharded split, executed (all ranks): rank r renders views r::N of EVERY frame, one frame at a time ----
+    # ---- the view-sharded split, executed (all ranks): rank r renders views r::N of EVERY frame ----
+    # `value`: the 64 independent frames of config 3, N of them per launch set (24 views per set at every N) and --frames-in-flight
+    # sets in flight; `sequential_frames`: one frame at a time on one stream, the schedule Topo4D's real loop allows (train.py:646).
     view_sharded = None
     if not by_views and not args.no_extras and args.config == "C2":
-        wv = Workload(args.config, args.opacity, dev, rank, world, 1, gather=dist is not None, view_shard=(rank, world), resident=4)
-        wv.learn_capacity()
+        def run_view_sharded(frames_per_launch, in_flight):
+            wv = Workload(args.config, args.opacity, dev, rank, world, in_flight, gather=dist is not None, view_shard=(rank, world),
+                          resident=4, frames_per_launch=frames_per_launch)
+            wv.learn_capacity()
 
-        def barrier_v():
-            wv.drain()
-            if dist is not None:
-                dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
-            torch.cuda.synchronize(dev)
-        dtv, _, stv = timed_run(wv, 50, 3, 0.05, barrier_v, all_reduce_max, regions=5, min_region_s=0.05)
-        view_sharded = {"parallelism": f"view-sharded x{world}: rank r renders views r::{world} of every frame ({wv.V} views per rank and frame), "
-                                       "loss all_gather per frame, one frame in flight (frames of the real loop are sequential, train.py:646)",
-                        "scaling": "strong", "views_per_rank": wv.V, "ms_per_frame": stv["ms_per_step"], "value": round(wv.full_views * 50 / dtv, 2),
-                        "unit": "views/s", "note": "strong-scaling speed-up at N GPUs = this value at N / this value at 1; the N = 1 line's `forecast` predicts it"}
-        del wv
+            def barrier_v():
+                wv.drain()
+                if dist is not None:
+                    dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
+                torch.cuda.synchronize(dev)
+            n_sets = max(2, 48 // frames_per_launch)
+            dtv, _, stv = timed_run(wv, n_sets, 3, 0.05, barrier_v, all_reduce_max, regions=5, min_region_s=0.05)
+            per_frame = {k: round(x / frames_per_launch, 4) for k, x in stv["ms_per_step"].items()}
+            r = {"views_per_rank_and_frame": wv.V, "frames_per_launch": frames_per_launch, "frames_in_flight_sets": wv.F, "ms_per_frame": per_frame,
+                 "value": round(wv.full_views * frames_per_launch * n_sets / dtv, 2), "unit": "views/s"}
+            del wv
+            return r
+        vs_batched = run_view_sharded(world, args.in_flight)
+        vs_seq = run_view_sharded(1, 1)
+        view_sharded = dict(vs_batched)
+        view_sharded.update({
+            "parallelism": f"view-sharded x{world}: rank r renders views r::{world} of every frame ({vs_batched['views_per_rank_and_frame']} views per rank and "
+                           f"frame); one launch set carries {world} consecutive frames of the 64-frame sequence (each with its own Gaussians: "
+                           "T4DProblem.views_per_param_set), loss all_gather per launch set",
+            "scaling": "strong", "views_per_rank": vs_batched["views_per_rank_and_frame"], "sequential_frames": vs_seq,
+            "note": "strong-scaling speed-up at N GPUs = this value at N / this value at 1 (the N = 1 line's `forecast` predicts it); "
+                    "`sequential_frames` = one frame at a time on one stream, what Topo4D's real loop (sequential frames, train.py:646) allows"})
 
     # ---- side measurements on one GPU ----
     scenario_b = single_view = drop_in = small_v = forecast = c4 = dense_1m = full_iteration = loss_k = bake = None
@@ -1090,15 +1148,17 @@ def main():
                 cpu = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         out = {
             "metric": "rasterizer fwd+bwd views/sec", "value": round(value, 2), "unit": "views/s",
-            "n_gpus": world, "steps": (my_steps * world if (args.scaling == "strong" and not by_views) else args.steps), "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / my_steps, 4), "higher_is_better": True, "scaling": args.scaling, "repeats": repeats,
+            "n_gpus": world, "steps": (my_steps * G if by_views else (my_steps * world if args.scaling == "strong" else args.steps)), "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / (my_steps * G), 4), "higher_is_better": True, "scaling": args.scaling, "repeats": repeats,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {V} views x {H}x{W}, P={P} vertex-bound Gaussians, "
                                    f"{'SH degree %d' % cfg['sh_degree'] if cfg['sh_degree'] is not None else 'precomputed RGB'}, "
                                    f"opacity scenario {args.opacity}, forward+backward, per-view gradients",
                        "views_per_step_per_gpu": V, "frames": wl.n_frames, "steps_per_rank": my_steps,
                        "parallelism": (f"view-sharded x{world}: rank r renders views r::{world} of every frame" +
+                                       (f", {G} frames per launch set" if G > 1 else ", one frame at a time (the real loop's frames are sequential)") +
                                        (", parameter gradients all-reduced" if args.allreduce_grads else "")) if by_views else f"frame-sharded x{world}",
+                       "frames_per_launch": G, "ms_per_launch_set": round(1e3 * dt / my_steps, 4),
                        "sync_mode": "lazy (capacity learned by checked warm-up)",
                        "host_enqueue_ms_per_step": round(1e3 * t_enqueue / my_steps, 4), "frames_in_flight": wl.F},
             "roofline": roofline, "cpu_baseline": cpu, "scenario_b": scenario_b, "single_view": single_view, "small_v": small_v,

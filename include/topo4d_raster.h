@@ -20,6 +20,7 @@
  *     stream unless T4D_FLAG_CHECKED / T4D_FLAG_DEBUG_SYNC asks for it.
  *   - one call renders n_views views of the SAME P Gaussians (the 24 cameras of a Topo4D frame, or one rank's
  *     shard of them); n_views = 1 is the reference's call shape.  All views share H and W.
+ *     (T4DProblem.views_per_param_set lets one call carry the views of SEVERAL frames, each frame with its own P Gaussians.)
  *   - per-view camera record = T4D_VIEW_FLOATS floats on the device, built from the fields of
  *     GaussianRasterizationSettings (helpers.py:73-86):
  *        [0..15]  viewmatrix  — the 16 floats of the [1,4,4] tensor helpers.py:67 builds (transposed w2c ⇒
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define T4D_ABI_VERSION 3
+#define T4D_ABI_VERSION 4
 #define T4D_VIEW_FLOATS 40
 #define T4D_GRAD_PAIR_FLOATS 10   /* per (Gaussian,tile) partial-gradient record in the backward scratch */
 
@@ -93,7 +94,15 @@ typedef struct T4DProblem {
     float   scale_modifier;
     int64_t pair_capacity;   /* capacity, PER VIEW, of the (Gaussian,tile) pair arena */
     uint32_t flags;
-    uint32_t reserved;
+    uint32_t views_per_param_set; /* 0 (or n_views): every view renders the same P Gaussians - one frame per call.
+                                     k > 0: the call carries n_views / k PARAMETER SETS (frames) of P Gaussians each, view v renders
+                                     set v / k; every per-Gaussian INPUT array (means3D, opacities, scales, rotations,
+                                     cov3D_precomp, colors_precomp, shs) then holds the sets one after the other, [n_views / k][P, .].
+                                     n_views must be a multiple of k.  Outputs and gradients keep their per-view layout ([V, ...]),
+                                     so nothing else changes: a rank of a view-sharded job (BASELINE config 3: 3 of 24 cameras per
+                                     rank) renders its cameras of several independent frames in ONE launch set, at the efficiency
+                                     of a 24-view launch.  Results per view are those of the same view in a one-frame call of the
+                                     same launch shape */
 } T4DProblem;
 
 typedef struct T4DStatus {

@@ -104,21 +104,30 @@ def test_the_drivers_two_gpu_command_carries_every_multi_rank_object():
 def test_view_sharded_two_rank_dry_run_equals_the_24_view_launch():
     """`bench.py --shard views` (the split of SURVEY 8e / BASELINE config 3: rank r renders views r::N of every frame): two ranks
     share the test GPU, gloo stands in for RCCL.  A view's loss scalar and its gradients do not depend on which other views
-    share its launch, so the gathered per-view losses of the two 12-view launches equal those of the one 24-view launch bit for
-    bit, and so do rank 0's per-view gradient checksums (views 0, 2, 4, ...).  The same command with ONE RCCL rank runs too."""
+    share its launch, so the gathered per-view losses of the two ranks' launch sets (12 cameras x 2 consecutive frames each: the
+    default --frames-per-launch is the number of ranks) equal those of the one-GPU run's 24-view launches bit for bit, and so do
+    rank 0's per-view gradient checksums (views 0, 2, 4, ...).  The same command with ONE RCCL rank runs too."""
     common = ["--steps", "2", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--shard", "views"]
     env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="2")
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common, env)
-    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="2"))
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="4"))
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "view-sharded x2" in two["config"]["parallelism"]
     assert two["config"]["views_per_step_per_gpu"] == 12 and one["config"]["views_per_step_per_gpu"] == 24
-    l2 = np.asarray(two["gathered_losses_first_steps"], np.float32)          # [step, rank-major 2 x 12]
-    l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [step, 24]
-    np.testing.assert_array_equal(l2.reshape(2, 2, 12).transpose(0, 2, 1).reshape(2, 24), l1)
-    g2 = np.asarray(two["grad_checksums_first_steps_rank0"], np.float64)     # rank 0's views: 0, 2, 4, ...
+    assert two["config"]["frames_per_launch"] == 2 and one["config"]["frames_per_launch"] == 1
+    l2 = np.asarray(two["gathered_losses_first_steps"], np.float32)          # [launch set, rank-major 2 x (2 frames x 12 views)]
+    l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [frame, 24]
+    assert l2.shape == (2, 48) and l1.shape == (4, 24)
+    np.testing.assert_array_equal(l2.reshape(2, 2, 2, 12).transpose(0, 2, 3, 1).reshape(4, 24), l1)      # (set, frame, view j, rank) -> view 2 j + rank
+    g2 = np.asarray(two["grad_checksums_first_steps_rank0"], np.float64)     # rank 0's views: 0, 2, 4, ... of two frames per set
     g1 = np.asarray(one["grad_checksums_first_steps_rank0"], np.float64)
-    np.testing.assert_array_equal(g2, g1[:, 0::2])
+    np.testing.assert_array_equal(g2.reshape(4, 12), g1[:, 0::2])
+    # --frames-per-launch 1 (the real loop's schedule: one frame at a time): 12-view launches, whole tiles too - the same bits
+    seq = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--frames-per-launch", "1"] + common, env)
+    assert seq["config"]["frames_per_launch"] == 1 and seq["config"]["frames_in_flight"] == 1
+    ls = np.asarray(seq["gathered_losses_first_steps"], np.float32)          # [frame, rank-major 2 x 12]
+    np.testing.assert_array_equal(ls.reshape(2, 2, 12).transpose(0, 2, 1).reshape(2, 24), l1[:2])
     assert np.isfinite(l1).all() and np.abs(l1).max() > 0 and np.abs(g1).max() > 0
     # views/s counts whole frames: 24 views per step over all ranks
     assert abs(two["value"] - 24 * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-3 * two["value"]
@@ -142,17 +151,35 @@ def test_strong_scaling_rounds_the_job_up_to_whole_steps_per_rank():
 
 def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
     """BASELINE config 3's split at its real width: EIGHT ranks (sharing the test GPU, gloo for RCCL), three views per rank and
-    frame, the driver's launch line.  A three-view launch runs the depth-SEGMENTED backward, whose replay starts
-    from the forward's snapshots: its sums - and the per-view scalar <colour, dL/dcolour> the ranks gather, a by-product of that
-    replay - agree with the whole-tile replay of the 24-view launch to summation-order rounding, not bit for bit (the two-rank
-    test, 12 views per launch, is the bit-for-bit one).  What IS exact: every view lands in its slot of the gathered vector."""
+    frame, the driver's launch line.
+    Default (--frames-per-launch = 8): a rank's launch set carries its 3 cameras of 8 consecutive frames, each frame with its own
+    Gaussians (T4DProblem.views_per_param_set) - 24 views, the launch shape of the one-GPU run: per view the gathered loss scalars
+    and rank 0's gradient checksums equal the one-GPU run's BIT FOR BIT.
+    --frames-per-launch 1 (one frame at a time, the real loop's schedule): a three-view launch runs the depth-SEGMENTED backward
+    (DESIGN section 5), whose replay starts from the forward's snapshots: its sums - and the per-view scalar <colour, dL/dcolour>
+    the ranks gather, a by-product of that replay - agree with the whole-tile replay of the 24-view launch to summation-order
+    rounding.  What IS exact there: every view lands in its slot of the gathered vector."""
     common = ["--steps", "2", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--shard", "views"]
-    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="2")
+    env = dict(os.environ, T4D_BENCH_SHARE_GPU="1", T4D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_BENCH_DUMP_LOSSES="1")
+    batched = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), "bench.py", "--gpus", "8"] + common, env)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="8"))
+    assert batched["n_gpus"] == 8 and batched["config"]["frames_per_launch"] == 8 and batched["config"]["views_per_step_per_gpu"] == 3
+    assert batched["steps"] == 8 and "8 frames per launch set" in batched["config"]["parallelism"]
+    lb = np.asarray(batched["gathered_losses_first_steps"], np.float32)       # [1 launch set, rank-major 8 x (8 frames x 3 views)]
+    l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)           # [8 frames, 24]
+    assert lb.shape == (1, 192) and l1.shape == (8, 24)
+    np.testing.assert_array_equal(lb.reshape(8, 8, 3).transpose(1, 2, 0).reshape(8, 24), l1)           # (rank, frame, view j) -> frame, view 8 j + rank
+    gb = np.asarray(batched["grad_checksums_first_steps_rank0"], np.float64)  # rank 0: 8 frames x views 0, 8, 16
+    g1 = np.asarray(one["grad_checksums_first_steps_rank0"], np.float64)
+    np.testing.assert_array_equal(gb.reshape(8, 3), g1[:, 0::8])
+    env = dict(env, T4D_BENCH_DUMP_LOSSES="2")
+    common = common + ["--frames-per-launch", "1"]
     eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                   "--master-port", str(_free_port()), "bench.py", "--gpus", "8"] + common, env)
-    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ, T4D_BENCH_DUMP_LOSSES="2"))
+    l1, g1 = l1[:2], g1[:2]
     assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and "view-sharded x8" in eight["config"]["parallelism"]
-    assert eight["config"]["views_per_step_per_gpu"] == 3
+    assert eight["config"]["views_per_step_per_gpu"] == 3 and eight["config"]["frames_per_launch"] == 1
     l8 = np.asarray(eight["gathered_losses_first_steps"], np.float32)        # [step, rank-major 8 x 3]
     l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [step, 24]
     unit_order = l8.reshape(2, 8, 3).transpose(0, 2, 1).reshape(2, 24)
@@ -160,7 +187,6 @@ def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
     # the 24 scalars of a frame are all different: a view in the wrong slot would be off by orders of magnitude more
     assert np.abs(l1[0][:, None] - l1[0][None, :])[~np.eye(24, dtype=bool)].min() > 100 * np.abs(unit_order - l1).max()
     g8 = np.asarray(eight["grad_checksums_first_steps_rank0"], np.float64)
-    g1 = np.asarray(one["grad_checksums_first_steps_rank0"], np.float64)
     np.testing.assert_allclose(g8, g1[:, 0::8], rtol=1e-5)
     assert np.isfinite(l1).all() and np.abs(l1).max() > 0
     # the same three views per launch in ONE process (the segmented build on both sides): bit for bit

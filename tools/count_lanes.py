@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Counting build of the render kernels (GPU box): what their visit loops do on BASELINE config 2 / 4, per 24-view launch.
-    tools/ab_build.sh count -DT4D_COUNT && T4D_LIB=topo4d_amd/csrc/variants/lib_count.so python tools/count_lanes.py [C2|C4] [A|B]
+    python tools/experiments/counting_build.py && T4D_LIB=topo4d_amd/csrc/variants/lib_count.so python tools/count_lanes.py [C2|C4] [A|B]
 Prints one JSON object: wave-steps, row-visits, contributing lanes -> useful-lane fraction and row balance of both kernels."""
 import ctypes as C, json, os, sys
 import torch

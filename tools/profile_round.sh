@@ -13,7 +13,7 @@ PROF_CMD="python $ROOT/tools/prof_single_view.py" tools/prof.sh ${R}_single_view
 PROF_CMD="python $ROOT/tools/loss_prof.py" tools/prof.sh ${R}_loss > /dev/null 2>&1                  # fused photometric loss, 24 x 512^2
 ( export TMPDIR=/tmp; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_gi -o t -- python $ROOT/tools/prof_graphed_iteration.py > /dev/null 2>&1; cp /tmp/${R}_gi/t_kernel_stats.csv $ROOT/gpurun_out/${R}_graphed_iteration_kernel_stats.csv )   # the launches of one replayed iteration
 python tools/sweep_loss_kernels.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_loss_sweep.txt
-tools/ab_build.sh count -DT4D_COUNT > /dev/null 2>&1
+python tools/experiments/counting_build.py > /dev/null 2>&1       # the shipped sources carry no counting hooks: an instrumented copy
 for a in "C2 A" "C2 B" "C4 A"; do T4D_LIB=$ROOT/topo4d_amd/csrc/variants/lib_count.so python tools/count_lanes.py $a --merge 2>/dev/null | tail -1; done > gpurun_out/${R}_lanes.jsonl
 # the counters go into profiles/*.json HERE too (the box's copy), so that the bench lines below carry them as "current";
 # profiles/ does not travel back: the same merges are repeated in the repository from gpurun_out/ (see profiles/README.md)

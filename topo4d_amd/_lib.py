@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # is still no fallback - a path that does not load raises.
 LIB_PATH = os.environ.get("T4D_LIB") or os.path.join(HERE, "csrc", "libtopo4d_raster.so")
 
-T4D_ABI_VERSION = 3
+T4D_ABI_VERSION = 4
 T4D_VIEW_FLOATS = 40
 T4D_GRAD_PAIR_FLOATS = 10
 
@@ -41,7 +41,7 @@ class T4DProblem(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_views", C.c_int32), ("P", C.c_int32), ("H", C.c_int32),
                 ("W", C.c_int32), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
                 ("scale_modifier", C.c_float), ("pair_capacity", C.c_int64), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("views_per_param_set", C.c_uint32)]
 
 
 class T4DStatus(C.Structure):

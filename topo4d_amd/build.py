@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("T4D_CFLAGS", "").split()          # e.g. -DT4D_ABL=2 for the ablation builds of tools/ablate.sh
+    extra = os.environ.get("T4D_CFLAGS", "").split()          # e.g. -DT4D_FWD_BATCH=128 (tuning constants only: the sources carry no experiment switches)
     cmd = [hipcc] + FLAGS + extra + ["-shared"] + sources() + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)

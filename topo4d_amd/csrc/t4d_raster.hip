@@ -52,14 +52,6 @@
 
 namespace {
 
-// T4D_ABL (ablation builds, tools/ablate.sh; never defined in the shipped library) - whole phases only, nothing inside the step
-// bodies of the render kernels (the in-step ablations and the s_memtime stamps of rounds 2-3 are recorded, with their numbers, in
-// tools/experiments/README.md):
-//   3 = backward: skip the whole visit loop (staging + write-out only) 4 = forward: skip blending (alpha evaluation only)
-//   5 = forward: skip the whole visit loop      6 / 7 = preprocess: stop before / after the pair-slot allocation
-#ifndef T4D_ABL
-#define T4D_ABL 0
-#endif
 constexpr int kBlock = 256;          // threads per workgroup everywhere (4 wave64)
 #ifndef T4D_FWD_BATCH
 #define T4D_FWD_BATCH 192
@@ -237,6 +229,7 @@ struct KP {
     unsigned long long *host_status;  // T4D_FLAG_ASYNC_STATUS on a one-view launch: the caller's pinned 16 bytes, written by the kernel itself
     // (behind everything else: the kernels of every other launch shape read their arguments from the offsets they always had)
     uint32_t seg_min_pairs;          // tiles of fewer pairs are not segmented (0: every tile is - small launches; kSegLongMin: seg_mode 2)
+    uint32_t views_per_set;          // T4DProblem.views_per_param_set: view v reads the per-Gaussian inputs of parameter set v / views_per_set (0: one set for all views)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -274,6 +267,14 @@ __device__ __forceinline__ ViewRecord load_view_record(const float *views, const
     for (int i = 0; i < 3; i++) { r.campos[i] = p[32 + i]; r.bg[i] = p[35 + i]; }
     r.tanx = p[38]; r.tany = p[39];
     return r;
+}
+
+// First row of view v's parameter set in the per-Gaussian INPUT arrays (means3D, opacities, scales, rotations, cov3D_precomp,
+// colors_precomp, shs): a launch may carry the views of several frames - T4DProblem.views_per_param_set consecutive views per
+// frame, the frames' parameters one [P, .] block after the other.  v is workgroup-uniform everywhere: one scalar division.
+__device__ __forceinline__ size_t param_row0(const KP &kp, const int v)
+{
+    return kp.views_per_set ? (size_t)((uint32_t)v / kp.views_per_set) * (size_t)kp.P : (size_t)0;
 }
 
 // wave64 inclusive prefix sum (uint32)
@@ -424,12 +425,8 @@ __device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float b
 // parameter rows (at config 4: 48 KiB of SH coefficients).  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so the
 // index is decoded such that ALL V workgroups of a block land on the SAME XCD, back to back: blocks go in groups of eight
 // (one per XCD), a group takes 8 V consecutive indices, view-major.  The rows then leave HBM once, not once per XCD (the
-// view-fastest order of round 2) or once per view (block-fastest).  T4D_GB_ORDER: bit 0 k_preprocess, bit 1
-// k_preprocess_bwd, bit 2 k_sh_bwd take this order (experiments; default: the two backward kernels - k_preprocess is a
-// third SLOWER with it, 211 -> 288 us at config 4, although its fetch traffic falls).
-#ifndef T4D_GB_ORDER
-#define T4D_GB_ORDER 6
-#endif
+// view-fastest order of round 2) or once per view (block-fastest).  k_preprocess_bwd and the SH backward kernels take this order;
+// k_preprocess does not: it is a third SLOWER with it (211 -> 288 us at config 4) although its fetch traffic falls.
 __device__ __forceinline__ bool block_and_view(const uint32_t b, const uint32_t V, const uint32_t nblocks, uint32_t &gb, uint32_t &v)
 {
     const uint32_t per = 8u * V, grp = b / per, rem = b - grp * per;
@@ -554,6 +551,8 @@ int check_problem(const T4DProblem *p)
     if ((int64_t)p->n_views * ((p->W + T4D_TILE_X - 1) / T4D_TILE_X) * ((p->H + T4D_TILE_Y - 1) / T4D_TILE_Y) > (1LL << 30))
         return fail(T4D_ERR_ARG, "n_views * tiles exceeds 2^30 work items: split the batch");
     if (p->pair_capacity < 1 || p->pair_capacity > 0x7fffffffLL) return fail(T4D_ERR_ARG, "pair_capacity out of range");
+    if (p->views_per_param_set != 0u && (p->views_per_param_set > (uint32_t)p->n_views || (uint32_t)p->n_views % p->views_per_param_set != 0u))
+        return fail(T4D_ERR_ARG, "n_views must be a multiple of views_per_param_set");
     if (p->sh_coeffs < 0 || p->sh_degree < 0 || p->sh_degree > 3) return fail(T4D_ERR_ARG, "sh_degree must be 0..3");
     if (p->sh_coeffs > 0 && p->sh_coeffs < (p->sh_degree + 1) * (p->sh_degree + 1))
         return fail(T4D_ERR_ARG, "sh_coeffs smaller than (sh_degree+1)^2");
@@ -569,6 +568,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.deg = p.sh_degree; kp.M = p.sh_coeffs;
     kp.scale_modifier = p.scale_modifier;
     kp.raw_params = (p.flags & T4D_FLAG_RAW_PARAMS) ? 1 : 0;
+    kp.views_per_set = (p.views_per_param_set != 0u && p.views_per_param_set < (uint32_t)p.n_views) ? p.views_per_param_set : 0u;
     kp.cap = (uint32_t)p.pair_capacity;
     {
         const uint32_t n_wg = (uint32_t)((p.P + kBlock - 1) / kBlock);
@@ -902,7 +902,8 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     if (kp.shs)
     {
         const bool plain = getenv("T4D_SH_BWD_PLAIN") != nullptr;                // tests / experiments: the general kernel also for degree 3
-        if (kp.M == 16 && kp.deg == 3 && !plain)
+        // (k_sh_bwd16 serves T4D_SHB_VIEWS views from one fetch of the coefficient rows: they must belong to one parameter set)
+        if (kp.M == 16 && kp.deg == 3 && !plain && (kp.views_per_set == 0u || kp.views_per_set % T4D_SHB_VIEWS == 0u))
             hipLaunchKernelGGL(k_sh_bwd16, dim3(gaussian_grid(p.P, (p.n_views + T4D_SHB_VIEWS - 1) / T4D_SHB_VIEWS)), dim3(kBlock), 0, stream, kp);
         else
             hipLaunchKernelGGL(k_sh_bwd, dim3(gaussian_grid(p.P, p.n_views)), dim3(kBlock), 0, stream, kp);
@@ -912,17 +913,6 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     return T4D_OK;
 }
 
-#ifdef T4D_COUNT
-T4D_EXPORT int t4d_debug_read_counters(unsigned long long *out, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_count), sizeof(unsigned long long) * 16);
-    if (e == hipSuccess && reset) {
-        const unsigned long long z[16] = { 0 };
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_count), z, sizeof(z));
-    }
-    return (int)e;
-}
-#endif
 
 
 T4D_EXPORT int t4d_profile_begin(void)

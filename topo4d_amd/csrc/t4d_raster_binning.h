@@ -26,22 +26,23 @@ __device__ __forceinline__ void preprocess_body(const KP &kp, const uint32_t gb,
     const ViewRecord vrec = load_view_record(kp.views, v);
     const float *view = vrec.view, *proj = vrec.proj;
     const size_t vg = (size_t)v * kp.P + g;
+    const size_t gp = param_row0(kp, v) + (size_t)g;          // row of this Gaussian in its view's parameter set
 
     uint32_t tiles = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     if (g < kp.P) {
-        const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+        const float mean[3] = { kp.means3D[3 * gp], kp.means3D[3 * gp + 1], kp.means3D[3 * gp + 2] };
         // (covariance parameters and opacity are requested together with the mean, not behind the near-plane test)
         float cov3_in[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, sc[3] = { 0.f, 0.f, 0.f };
         float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
         if (kp.cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) cov3_in[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+            for (int k = 0; k < 6; k++) cov3_in[k] = kp.cov3D_precomp[6 * gp + k];
         } else {
-            sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
-            q = reinterpret_cast<const float4 *>(kp.rotations)[g];
+            sc[0] = kp.scales[3 * gp]; sc[1] = kp.scales[3 * gp + 1]; sc[2] = kp.scales[3 * gp + 2];
+            q = reinterpret_cast<const float4 *>(kp.rotations)[gp];
         }
-        float opacity = kp.opacities[g];
+        float opacity = kp.opacities[gp];
         if (kp.raw_params) {                             // T4D_FLAG_RAW_PARAMS: the optimiser's parameters (helpers.py:95-97)
             opacity = t4d_act_sigmoid(opacity);
             if (!kp.cov3D_precomp) {
@@ -90,14 +91,14 @@ __device__ __forceinline__ void preprocess_body(const KP &kp, const uint32_t gb,
                     kp.xy[vg] = make_float2(px, py);
                     kp.depth[vg] = pvz;
                     kp.conic_opacity[vg] = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacity);
-                    if (kp.shs && T4D_ABL != 8) {
+                    if (kp.shs) {
                         float d[3] = { mean[0] - vrec.campos[0], mean[1] - vrec.campos[1], mean[2] - vrec.campos[2] };
                         const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
                         d[0] /= len; d[1] /= len; d[2] /= len;
                         float bas[16];
                         sh_basis(kp.deg, d, bas);
                         const int K = (kp.deg + 1) * (kp.deg + 1);
-                        const float *sh = kp.shs + (size_t)g * kp.M * 3;
+                        const float *sh = kp.shs + gp * kp.M * 3;
                         // a Gaussian's coefficients are 12*M contiguous bytes: fetch them as 16-byte loads when the row
                         // is 16-byte aligned (M % 4 == 0, e.g. the 16 coefficients of degree 3) instead of 3*K scalar
                         // loads at a 12*M-byte lane stride
@@ -134,9 +135,6 @@ __device__ __forceinline__ void preprocess_body(const KP &kp, const uint32_t gb,
         kp.radii[vg] = radius;
     }
 
-#if T4D_ABL == 6
-    return;
-#endif
     // ---- pair slots: block-local exclusive scan, ONE returning atomic per workgroup on the view's cursor ----
     const uint32_t incl = wave_incl_scan(tiles);
     const int wave = tid >> 6, lane = tid & 63;
@@ -180,9 +178,6 @@ __device__ __forceinline__ void preprocess_body(const KP &kp, const uint32_t gb,
     // Gaussians of one workgroup are usually neighbours on the mesh, so they hit few distinct tiles: count them in an
     // LDS histogram over the workgroup's tile bounding box and send ONE returning global atomic per touched tile
     // (instead of one per pair).  Bounding boxes larger than the histogram fall back to per-pair global atomics.
-#if T4D_ABL == 7
-    return;
-#endif
     uint32_t *cnt = kp.tile_count + (size_t)v * kp.T;
     uint32_t *prank = kp.pair_rank + (size_t)v * kp.cap;
     const int bbx = s_bb[0], bby = s_bb[1], bw = s_bb[2] - s_bb[0], bh = s_bb[3] - s_bb[1];
@@ -221,12 +216,8 @@ __global__ __launch_bounds__(kBlock) void k_preprocess(const KP kp)
 {
     const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
     uint32_t gb, vb;
-#if T4D_GB_ORDER & 1
-    if (!block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, gb, vb)) return;          // padding of the last group of eight
-#else
     vb = blockIdx.x / nblocks; gb = blockIdx.x - vb * nblocks;
     if (vb >= (uint32_t)kp.V) return;
-#endif
     PreOut po;
     preprocess_body(kp, gb, vb, po);
 }

@@ -14,12 +14,7 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
     const uint32_t n_pv = gaussian_grid(kp.P, kp.V);
     const bool spare = blockIdx.x >= n_pv;
     uint32_t gb = 0, vb = 0;
-#if T4D_GB_ORDER & 2
     if (!spare && !block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, gb, vb)) return;
-#else
-    gb = blockIdx.x / (uint32_t)kp.V; vb = blockIdx.x - gb * (uint32_t)kp.V;
-    if (!spare && gb >= nblocks) return;
-#endif
     const int v = spare ? (int)(blockIdx.x - n_pv) : (int)vb;
     const int g = (int)gb * kBlock + threadIdx.x;
     if (spare) {
@@ -43,6 +38,7 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
     }
     if (g >= kp.P) return;
     const size_t vg = (size_t)v * kp.P + g;
+    const size_t gp = param_row0(kp, v) + (size_t)g;          // row of this Gaussian in its view's parameter set
     const ViewRecord vrec = load_view_record(kp.views, v);
     const float *view = vrec.view, *proj = vrec.proj;
     // Everything that depends on (view, Gaussian) alone is requested HERE, before any of it is used: as the kernel was written
@@ -53,16 +49,16 @@ __device__ __forceinline__ void preprocess_bwd(const KP &kp)
     const float2 p2 = kp.xy[vg];
     const uint32_t base = kp.pair_off[vg];
     const float4 cq = kp.conic_opacity[vg];
-    const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+    const float mean[3] = { kp.means3D[3 * gp], kp.means3D[3 * gp + 1], kp.means3D[3 * gp + 2] };
     float cov3_in[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
     float sc[3] = { 0.f, 0.f, 0.f };
     if (kp.cov3D_precomp) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) cov3_in[k] = kp.cov3D_precomp[6 * (size_t)g + k];
+        for (int k = 0; k < 6; k++) cov3_in[k] = kp.cov3D_precomp[6 * gp + k];
     } else {
-        sc[0] = kp.scales[3 * (size_t)g]; sc[1] = kp.scales[3 * (size_t)g + 1]; sc[2] = kp.scales[3 * (size_t)g + 2];
-        q = reinterpret_cast<const float4 *>(kp.rotations)[g];
+        sc[0] = kp.scales[3 * gp]; sc[1] = kp.scales[3 * gp + 1]; sc[2] = kp.scales[3 * gp + 2];
+        q = reinterpret_cast<const float4 *>(kp.rotations)[gp];
     }
     const float4 q_raw = q;
     if (kp.raw_params && !kp.cov3D_precomp) {            // T4D_FLAG_RAW_PARAMS: activate as the forward did
@@ -239,12 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
     const int tid = threadIdx.x;
     const uint32_t nblocks = (uint32_t)(kp.P + kBlock - 1) / kBlock;
     uint32_t pblock, vb;
-#if T4D_GB_ORDER & 4
     if (!block_and_view(blockIdx.x, (uint32_t)kp.V, nblocks, pblock, vb)) return;
-#else
-    pblock = blockIdx.x / (uint32_t)kp.V; vb = blockIdx.x - pblock * (uint32_t)kp.V;
-    if (pblock >= nblocks) return;
-#endif
     const int v = (int)vb;
     const int g0 = (int)pblock * kBlock;
     const int n = min(kBlock, kp.P - g0);                // Gaussians of this workgroup
@@ -253,6 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
     if (tid < n) {
         const int g = g0 + tid;
         const size_t vg = (size_t)v * kp.P + g;
+        const size_t gp = param_row0(kp, v) + (size_t)g;
         // a truncated forward (arena overflow without T4D_FLAG_CHECKED) returns zero gradients everywhere
         const bool vis = kp.status->overflow == 0u && kp.radii[vg] > 0;
         float gc[3] = { 0.f, 0.f, 0.f };
@@ -261,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
         for (int i = 0; i < 16; i++) bas[i] = 0.f;
         if (vis) {
             const float *vr = kp.views + (size_t)v * T4D_VIEW_FLOATS;
-            const float d0[3] = { kp.means3D[3 * (size_t)g] - vr[32], kp.means3D[3 * (size_t)g + 1] - vr[33], kp.means3D[3 * (size_t)g + 2] - vr[34] };
+            const float d0[3] = { kp.means3D[3 * gp] - vr[32], kp.means3D[3 * gp + 1] - vr[33], kp.means3D[3 * gp + 2] - vr[34] };
             const float len = sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
             const float d[3] = { d0[0] / len, d0[1] / len, d0[2] / len };
             float bx[16], by[16], bz[16];
@@ -272,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd(const KP kp)
             gc[0] = (cl & 1u) ? 0.f : grgb[0]; gc[1] = (cl & 2u) ? 0.f : grgb[1]; gc[2] = (cl & 4u) ? 0.f : grgb[2];
             const int K = (kp.deg + 1) * (kp.deg + 1);
             float gd[3] = { 0.f, 0.f, 0.f };
-            const float *sh = kp.shs + (size_t)g * M3;
+            const float *sh = kp.shs + gp * M3;
             if ((kp.M & 3) == 0 && K == 16) {            // degree 3, 16-byte aligned rows: twelve 16-byte loads, consumed as they come
                 const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
                 float c[48];
@@ -347,8 +339,11 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd16(const KP kp)
     if (!block_and_view(blockIdx.x, ngroups, nblocks, pblock, vgrp)) return;
     const int g0 = (int)pblock * kBlock;
     const int n = min(kBlock, kp.P - g0);                // Gaussians of this workgroup
+    // (several parameter sets per launch: the host takes this kernel only when a set's views fill whole groups, so the group's
+    // first view names the set of all of them)
+    const size_t row0 = param_row0(kp, (int)vgrp * T4D_SHB_VIEWS);
     {
-        const float4 *src = reinterpret_cast<const float4 *>(kp.shs + (size_t)g0 * 48);
+        const float4 *src = reinterpret_cast<const float4 *>(kp.shs + (row0 + (size_t)g0) * 48);
         for (int i = tid; i < n * 12; i += kBlock) {
             const int r = i / 12, part = i - r * 12;
             *reinterpret_cast<float4 *>(s_raw + r * kPitch + part * 4) = src[i];
@@ -363,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_bwd16(const KP kp)
     }
     __syncthreads();                                     // the rows are in registers: the staging area is free
     const int g = g0 + min(tid, n - 1);
-    const float mean[3] = { kp.means3D[3 * (size_t)g], kp.means3D[3 * (size_t)g + 1], kp.means3D[3 * (size_t)g + 2] };
+    const float mean[3] = { kp.means3D[3 * (row0 + (size_t)g)], kp.means3D[3 * (row0 + (size_t)g) + 1], kp.means3D[3 * (row0 + (size_t)g) + 2] };
     const bool truncated = kp.status->overflow != 0u;   // a truncated forward (arena overflow without T4D_FLAG_CHECKED): zero gradients
     const int v_end = min(kp.V, (int)(vgrp + 1u) * T4D_SHB_VIEWS);
     for (int v = (int)vgrp * T4D_SHB_VIEWS; v < v_end; v++) {

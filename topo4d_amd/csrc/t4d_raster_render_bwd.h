@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     const float *r2_in = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
-    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
+    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp + 3 * param_row0(kp, v);
     const int32_t *radii = kp.radii + (size_t)v * kp.P;
     const uint32_t *pair_off = kp.pair_off + (size_t)v * kp.P;
     float2 *grad_pair = reinterpret_cast<float2 *>(kp.grad_pair) + (size_t)v * kp.cap * (kGP / 2);
@@ -391,8 +391,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             for (int c2 = 0; c2 < kChunks; c2++) conflict_s[c2] = uniform_u64(conflict[c2]);
             const unsigned short *list = s_list[wave][row];
             const unsigned char *rec_b = s_rec;
-            T4D_COUNT_ADD(1, 1); T4D_COUNT_ADD(2, (nsteps + 3) & ~3); T4D_COUNT_ADD(3, cnts[0] + cnts[1] + cnts[2] + cnts[3]);
-            if (bi == nb - 1 && wave == 0) T4D_COUNT_ADD(0, 1);
             // LAT: lanes that keep no sum write (zeros plus whatever) into distinct floats of the null splat's row of their slab
             unsigned char *slab = LAT ? reinterpret_cast<unsigned char *>(my_slot >= 0 ? &s_acc[wave * 4 + row][0][my_slot]
                                                                                       : &s_acc[wave * 4 + row][kNull][(lane & 15) % kAcc])
@@ -400,9 +398,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
             const uint32_t slab_and = (!LAT || my_slot >= 0) ? 0xffffffffu : 0u;       // slot-less lanes of the latency build stay on their dummy float
             // entry of the first staged splat this pixel did NOT see in the forward pass (entries are slot * kEnt)
             const int lc_rel = (int)min(last_contributor - min(last_contributor, lo), (uint32_t)kBwdBatch) * kEnt;
-#if T4D_ABL == 3
-            nsteps = 0;
-#endif
             // The loop is arranged so that no LDS round trip sits between dependent instructions: the list entries of the
             // NEXT group are fetched while this group is processed, the colour records are fetched together with the
             // geometry records, and a step's slab value is read BEFORE its arithmetic and written back after it
@@ -429,9 +424,6 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool contrib = contribs[u];
-#ifdef T4D_COUNT
-                    { const unsigned long long cb_ = __ballot(contrib); T4D_COUNT_ADD(4, __builtin_popcountll(cb_)); }
-#endif
                     const v2f d = ds[u];
                     const float G = Gs[u], alpha = alphas[u];
                     float *dst = reinterpret_cast<float *>(slab + (LAT ? (ee[u] & slab_and) : ee[u]));
@@ -458,12 +450,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
                         // 0.5*W, -0.5 ...) is applied ONCE per Gaussian after all tiles are summed (k_preprocess_bwd).
                         const float4 cd = cds[u];
                         const float om = 1.f - alpha;                              // >= 0.01
-#ifdef T4D_RCP_NEWTON     // experiment (tools/ab_build.sh newton -DT4D_RCP_NEWTON): 1 / (1 - alpha) to within half an ulp; see DESIGN.md section 2
-                        const float inv0 = __builtin_amdgcn_rcpf(om);
-                        const float inv = fmaf(fmaf(-om, inv0, 1.f), inv0, inv0);
-#else
-                        const float inv = __builtin_amdgcn_rcpf(om);
-#endif
+                        const float inv = __builtin_amdgcn_rcpf(om);          // (a Newton step on it: +1.9 % of the kernel, no decision depends on it - tools/experiments/README.md)
                         T = T * inv;
                         w = alpha * T;
                         float q = fmaf(cd.x, dp01.x, fmaf(cd.y, dp01.y, cd.z * dp2));

@@ -16,16 +16,6 @@
 // ---------------------------------------------------------------------------------------------------------
 constexpr float kLog2e = 1.4426950408889634f;
 
-// Counting build (-DT4D_COUNT, tools/count_lanes.py; never defined in the shipped library): what the render kernels' visit loops
-// do, summed over a launch - [0..7] backward, [8..15] forward:
-//   +0 non-empty tiles   +1 live wave-batches   +2 wave-steps (one step = four DPP rows x 16 pixels)   +3 row-visits (list entries)
-//   +4 lanes that blend / contribute (of 64 per wave-step)
-#ifdef T4D_COUNT
-__device__ unsigned long long g_count[16];
-#define T4D_COUNT_ADD(IDX_, VAL_) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_count[(IDX_)], (unsigned long long)(VAL_)); } while (0)
-#else
-#define T4D_COUNT_ADD(IDX_, VAL_) do { } while (0)
-#endif
 
 __device__ __forceinline__ void tile_pixel(int tid, int tx, int ty, int &px, int &py)
 {
@@ -250,7 +240,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     float *r2_out = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
     const float4 *co = kp.conic_opacity + (size_t)v * kp.P;
-    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
+    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp + 3 * param_row0(kp, v);
     // segmented backward: this tile's snapshot slots (a tile of one segment keeps none: its replay starts at the list's end)
     float *snap = nullptr;
     if (SEG && n > (uint32_t)kSeg && n >= kp.seg_min_pairs)
@@ -353,8 +343,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
             }
         }
         if (done_m == ~0ull) continue;               // wave-uniform; still takes part in the barriers above
-        if (b == 0 && wave == 0) T4D_COUNT_ADD(8, 1);
-        T4D_COUNT_ADD(9, 1);
         uint32_t last_e = 0xffffffffu;               // entry of the last splat blended in this batch
 #pragma clang loop unroll(disable)
         for (int sub = 0; sub < kNSub; sub++) {      // (one round per batch unless SEG)
@@ -395,10 +383,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
         for (int r = 0; r < 4; r++) pad_visit_list<kU>(s_list[wave][r], cnts[r], nsteps, lane, (unsigned short)(kNull * kRec));
         __builtin_amdgcn_wave_barrier();
         const unsigned short *list = s_list[wave][row];
-        T4D_COUNT_ADD(11, cnts[0] + cnts[1] + cnts[2] + cnts[3]);
-#if T4D_ABL == 5
-        nsteps = 0;
-#endif
         for (int k = 0; k < nsteps; k += kU) {
             uint32_t e[kU];
 #pragma unroll
@@ -422,10 +406,6 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                     valid[u] = __ballot(!(p2 > 0.0f)) & __ballot(!(alpha[u] < T4D_ALPHA_MIN));
                 }
             }
-#if T4D_ABL == 4
-            if (alpha[0] + alpha[1] + alpha[2] + alpha[3] == 12345.f) C0 += 1.f;
-            continue;
-#endif
             // (no "does any lane blend?" test: with four different splats in flight per step the answer is almost always yes)
             if (LAT) {
                 // The latency build's blend: ONE wave per SIMD walks a dependent chain, so what counts is the LENGTH of the chain from
@@ -467,9 +447,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
                 D = fmaf(cd.w, w, D);
                 T = ok ? test_T : T;
                 last_e = ok ? e[u] : last_e;
-                T4D_COUNT_ADD(12, __builtin_popcountll(live & ~below));
             }
-            T4D_COUNT_ADD(10, kU);
             if (done_m == ~0ull) break;
         }
         if (SEG) {

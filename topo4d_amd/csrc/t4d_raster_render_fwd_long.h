@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
                 if (g < (uint32_t)kp.P) {                        // (stale entries of a truncated list are ignored)
                     const float2 p = kp.xy[(size_t)v * kp.P + g];
                     const float4 c = kp.conic_opacity[(size_t)v * kp.P + g];
-                    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp;
+                    const float *rgb = kp.shs ? kp.rgb + (size_t)v * kp.P * 3 : kp.colors_precomp + 3 * param_row0(kp, v);
                     unsigned char *rec = s_rec + tid * kRec;
                     head = make_float4(p.x, p.y, cutoff_radius2(c), 0.f);
                     *reinterpret_cast<float4 *>(rec + 16) = scale_conic(c);

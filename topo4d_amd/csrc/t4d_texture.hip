@@ -46,9 +46,6 @@ constexpr int kScanChunk = 1024;
 #ifndef T4D_TEX_GROUP
 #define T4D_TEX_GROUP 16               // lanes per triangle record in the texel loop (same box: 64 lanes 0.679 ms, 32: 0.638, 16: 0.622, 8: 0.640)
 #endif
-#ifndef T4D_TEX_ABL
-#define T4D_TEX_ABL 0                // timing experiments only (results wrong): 1 = no per-triangle texel loop, 2 = the write-out stores one float per texel
-#endif
 
 struct TexP {
     const float *vertices;
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
         // evaluates a texel does not matter: the LDS maximum is order-independent.
         constexpr int kG = T4D_TEX_GROUP, kPerWave = 64 / kG;             // lanes per record, records per wave at a time
         const int grp = lane / kG, hl = lane % kG;
-        for (int k0 = kPerWave * wave; k0 < ((T4D_TEX_ABL & 1) ? 0 : cnt); k0 += kPerWave * (kBlock / 64)) {
+        for (int k0 = kPerWave * wave; k0 < cnt; k0 += kPerWave * (kBlock / 64)) {
             const int k = k0 + grp;
             const bool have = k < cnt;
             const TriRec t = s_tri[have ? k : k0];
@@ -449,15 +446,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FRESH ? 
             const float px = (float)x, py = (float)y;
             const bool border = tile_border && (px < 2 || px > P.w - 3 || py < 2 || py > P.h - 3);
             const TriEval ev = eval_texel(s_tri[slot], px, py, border);
-#if T4D_TEX_ABL & 2
-            float acc = ev.pd;
-            for (int k = 0; k < P.c; k++) acc += ev.w0 * s_col[slot][0][k] + ev.w1 * s_col[slot][1][k] + ev.w2 * s_col[slot][2][k];
-            P.depth[o] = acc;
-#else
             for (int k = 0; k < P.c; k++)
                 P.image[o * P.c + k] = ev.w0 * s_col[slot][0][k] + ev.w1 * s_col[slot][1][k] + ev.w2 * s_col[slot][2][k];
             P.depth[o] = ev.pd;
-#endif
         }
         return;
     }

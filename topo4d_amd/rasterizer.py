@@ -422,15 +422,23 @@ class ViewBatch:
 
     Owns the opaque state buffer between forward and backward, like the (geomBuffer, binningBuffer, imgBuffer)
     byte tensors upstream keeps in its autograd ctx.
+
+    `param_sets = S > 1`: the V views belong to S independent frames, V / S consecutive views each (T4DProblem.views_per_param_set);
+    every per-Gaussian input of forward() then carries a leading set axis ([S,P,3] means3D, [S,P,1] opacities, ...), outputs and
+    gradients stay per view.  A view-sharded rank renders its few cameras of several frames in one launch set this way.
     """
 
     def __init__(self, views: torch.Tensor, H: int, W: int, scale_modifier: float = 1.0, sh_degree: int = 0,
-                 debug: bool = False, prefiltered: bool = False, cam_key=None, sync_mode: Optional[str] = None):
+                 debug: bool = False, prefiltered: bool = False, cam_key=None, sync_mode: Optional[str] = None,
+                 param_sets: int = 1):
         if not views.is_cuda:
             raise RuntimeError("topo4d_amd has no CPU path: tensors must live on a HIP device")
         self.lib = _lib.load()
         self.views = views if views.is_contiguous() else views.contiguous()
         self.V = int(views.shape[0])
+        self.param_sets = int(param_sets)
+        if self.param_sets < 1 or self.V % self.param_sets != 0:
+            raise ValueError("the number of views must be a multiple of param_sets")
         self.H, self.W = int(H), int(W)
         self.scale_modifier = float(scale_modifier)
         self.sh_degree = int(sh_degree)
@@ -488,7 +496,10 @@ class ViewBatch:
         means3D = _f32c(means3D, "means3D", dev)
         if means3D is None:
             raise ValueError("means3D must not be empty")
-        P = int(means3D.shape[0])
+        S = self.param_sets
+        if S > 1 and (means3D.dim() != 3 or means3D.shape[0] != S):
+            raise ValueError("param_sets > 1: means3D must be [S,P,3] (every per-Gaussian input carries the set axis)")
+        P = int(means3D.shape[-2])
         opacities = _f32c(opacities, "opacities", dev)
         scales = _f32c(scales, "scales", dev)
         rotations = _f32c(rotations, "rotations", dev)
@@ -500,13 +511,17 @@ class ViewBatch:
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        if opacities is None or opacities.numel() != P:
+        if opacities is None or opacities.numel() != S * P:
             raise ValueError("opacities must hold one value per Gaussian")
+        for name, t, width in (("scales", scales, 3), ("rotations", rotations, 4), ("colors_precomp", colors_precomp, 3),
+                               ("cov3D_precomp", cov3D_precomp, 6)):
+            if S > 1 and t is not None and t.numel() != S * P * width:
+                raise ValueError(f"param_sets > 1: {name} must be [S,P,{width}]")
         M = 0
         if shs is not None:
-            if shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3:
-                raise ValueError("shs must be [P, M, 3]")
-            M = int(shs.shape[1])
+            if shs.dim() != (3 if S == 1 else 4) or shs.shape[-3] != P or shs.shape[-1] != 3 or shs.numel() % (S * P * 3) != 0:
+                raise ValueError("shs must be [P, M, 3]" if S == 1 else "param_sets > 1: shs must be [S, P, M, 3]")
+            M = int(shs.shape[-2])
             if M < (self.sh_degree + 1) ** 2:
                 raise ValueError("shs holds fewer coefficients than sh_degree needs")
         V, H, W = self.V, self.H, self.W
@@ -538,7 +553,7 @@ class ViewBatch:
                 if track.need > 0.75 * cap:                       # grow well before the arena can overflow
                     scene.grow(_round_capacity(track.need))
                 cap = scene.capacity or cap
-        pkey = (V, M, self.sh_degree, self.scale_modifier)
+        pkey = (V, M, self.sh_degree, self.scale_modifier, S)
         plan = scene.plans.get(pkey)
         if plan is None:
             plan = scene.plans[pkey] = _Plan()
@@ -557,7 +572,7 @@ class ViewBatch:
             elif self.status_sink is not None and not checked:
                 flags |= _lib.T4D_FLAG_ASYNC_STATUS
                 status_arg = C.cast(C.c_void_p(int(self.status_sink)), C.POINTER(T4DStatus))
-            prob = T4DProblem(T4D_ABI_VERSION, V, P, H, W, self.sh_degree, M, self.scale_modifier, cap, flags, 0)
+            prob = T4DProblem(T4D_ABI_VERSION, V, P, H, W, self.sh_degree, M, self.scale_modifier, cap, flags, 0 if S == 1 else V // S)
             nbytes = plan.state_bytes.get(cap)
             if nbytes is None:
                 nbytes = plan.state_bytes[cap] = lib.t4d_state_bytes(C.byref(prob))
@@ -610,8 +625,8 @@ class ViewBatch:
                                "call .backward() on the loss instead of ViewBatch.backward()")
         dev = self.device
         means3D, opacities, scales, rotations, cov3D_precomp, colors_precomp, shs = self.inputs
-        V, P, H, W = self.V, int(means3D.shape[0]), self.H, self.W
-        M = 0 if shs is None else int(shs.shape[1])
+        V, P, H, W = self.V, int(means3D.shape[-2]), self.H, self.W
+        M = 0 if shs is None else int(shs.shape[-2])
         dL_dcolor = _f32c(dL_dcolor, "dL_dcolor", dev)
         if dL_dcolor is None or dL_dcolor.numel() != V * 3 * H * W:
             raise ValueError("dL_dcolor must be [V,3,H,W]")
