@@ -70,6 +70,9 @@ def algorithmic_bytes(P, R, HW, S=0):
         "k_render_bwd": HW * 32 + R * 44 + P * 44,        # pixel grads/state read + gather + intermediate grads write
         "k_preprocess_bwd": P * 44 + P * (80 + S) + P * (68 + S),
     }
+    # kernels that only run where tile lists are long (dense passes) work on a share of the bytes counted above for the kernel
+    # they relieve: no algorithmic bytes of their own
+    per_kernel.update({"k_sort_long": 0, "k_fwd_long": 0, "k_render_bwd_long": 0})
     total = P * (352 + 3 * S) + R * 120 + HW * 60
     return per_kernel, total
 
@@ -609,6 +612,27 @@ def dense_1m_probe(dev, reps=5):
     out = {"workload": "1 view per call, P=1000000, 4096x3008 (WxH), opacity scenario A, forward+backward through the C ABI",
            "ms_per_view": round(min(walls), 3), "ms_runs": [round(x, 3) for x in walls], "views_per_s": round(1e3 / min(walls), 1),
            "pairs": int(st.total_pairs), "longest_tile_list": int(st.max_tile_pairs), "kernels_us": kern}
+    # roofline of this one-view launch (SURVEY 8d's bytes with P = 10^6, the measured R, 12.3 M pixels): the pipeline as a whole and
+    # the dominant kernel - the backward replay, whose long tiles run in a launch of their own (k_render_bwd_long: same bytes, both
+    # durations).  The forward is k_render_fwd + the three depth-parallel launches of the long tiles (k_fwd_long).
+    per_k, total_b = algorithmic_bytes(1000000, int(st.total_pairs), H * W, 0)
+    t_bwd = kern.get("k_render_bwd", 0.0) + kern.get("k_render_bwd_long", 0.0)
+    t_fwd = kern.get("k_render_fwd", 0.0) + kern.get("k_fwd_long", 0.0)
+    t_sort = kern.get("k_sort_tiles", 0.0) + kern.get("k_sort_long", 0.0)
+    gbs = lambda b, us: round(b / (us * 1e-6) / 1e9, 1) if us > 0 else None
+    ach = gbs(per_k["k_render_bwd"], t_bwd)
+    out["roofline"] = {"bound": "hbm", "kernel": "k_render_bwd + k_render_bwd_long (the long tiles' depth-segmented replay)", "achieved": ach,
+                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4) if ach else None,
+                       "traffic": load_profile_json("traffic.json", "DENSE_1M_1V", "k_render_bwd"),
+                       "alg_bytes_per_launch": int(per_k["k_render_bwd"]), "avg_us": round(t_bwd, 1),
+                       "stages": {"render_bwd": {"us": round(t_bwd, 1), "alg_GBs": ach},
+                                  "render_fwd": {"us": round(t_fwd, 1), "alg_GBs": gbs(per_k["k_render_fwd"], t_fwd)},
+                                  "sort": {"us": round(t_sort, 1), "alg_GBs": gbs(per_k["k_sort_tiles"], t_sort)},
+                                  "preprocess": {"us": kern.get("k_preprocess"), "alg_GBs": gbs(per_k["k_preprocess"], kern.get("k_preprocess", 0.0))},
+                                  "preprocess_bwd": {"us": kern.get("k_preprocess_bwd"), "alg_GBs": gbs(per_k["k_preprocess_bwd"], kern.get("k_preprocess_bwd", 0.0))}},
+                       "pipeline_alg_bytes_per_view": int(total_b),
+                       "pipeline_frac_of_peak": round(total_b / (min(walls) * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                       "counters": counters_provenance("DENSE_1M_1V")}
     # The same scene from the rig's camera 4, which looks at a polar cap of the lat-long head: hundreds of tiles with lists of
     # 2,000 - 9,000 pairs (camera 12 above: one of 12,614).  Same wave-steps; what differs is how long the longest tiles keep
     # their workgroups (their backward is cut into depth segments).

@@ -259,10 +259,11 @@ int t4d_adam_pin_step(const T4DAdamTensor *tensors /* host array */, int32_t n_t
  * consecutive counters, all equal - read any of them).  A workgroup of a tensor that has a gradient advances its own counter, then
  * uses it for the bias corrections (a tensor skipped for lack of a gradient does not advance).  The `step` and `lr` fields of the
  * descriptors are ignored.  Bias corrections are evaluated in double precision on the device: results equal t4d_adam_pin_step's.
- * The descriptors' shapes must be the same in every call that shares a step_dev array. */
+ * The descriptors' shapes must be the same in every call that shares a step_dev array: n_step_counters - the length of step_dev -
+ * is checked against t4d_adam_step_counters(tensors, n_tensors) (T4D_ERR_ARG otherwise; nothing is launched). */
 int64_t t4d_adam_step_counters(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors);
 int t4d_adam_pin_step_graph(const T4DAdamTensor *tensors /* host array */, int32_t n_tensors, float beta1, float beta2, float eps,
-                            int32_t *step_dev, const float *lr_dev, void *hip_stream);
+                            int32_t *step_dev, int64_t n_step_counters, const float *lr_dev, void *hip_stream);
 
 /* Dense-attribute interpolation: helpers.py:237-253 `compute_vertex_attribute_by_weight_2` on the device (Topo4D runs it in
  * numpy after a device->host copy every frame, train.py:504-506).  out [n_coarse+n_dense, width]: the first n_coarse rows

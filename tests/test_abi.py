@@ -126,7 +126,8 @@ def test_every_compute_export_rejects_bad_arguments_before_touching_a_device():
     rejected(lib.t4d_adam_pin_step(arr(T(64, 64, None, 64, None, None, 4, 3, 1e-3, 1, 0)), 1, 0.9, 0.999, 1e-15, none))
     rejected(lib.t4d_adam_pin_step(arr(T(64, 64, 64, 64, 64, None, 4, 3, 1e-3, 1, 0)), 1, 0.9, 0.999, 1e-15, none))
     rejected(lib.t4d_adam_pin_step(arr(T(64, 64, 64, 64, None, None, 4, 3, 1e-3, 0, 0)), 1, 0.9, 0.999, 1e-15, none))
-    rejected(lib.t4d_adam_pin_step_graph(arr(ok), 1, 0.9, 0.999, 1e-15, none, one, none))
+    rejected(lib.t4d_adam_pin_step_graph(arr(ok), 1, 0.9, 0.999, 1e-15, none, 1, one, none))
+    rejected(lib.t4d_adam_pin_step_graph(arr(ok), 1, 0.9, 0.999, 1e-15, one, 2, one, none))       # a counter array of another layout
     assert lib.t4d_adam_step_counters(arr(ok, T(64, 64, 64, 64, None, None, 1000, 3, 1e-3, 1, 0)), 2) == 1 + 12
     assert lib.t4d_adam_step_counters(None, 2) == 0
     # activations, dense interpolation, view sums and dots, visibility

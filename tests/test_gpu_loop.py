@@ -50,6 +50,55 @@ def test_fused_adam_matches_torch_adam_and_pins():
     assert torch.equal(pb['means3D'][static], static_verts)
 
 
+def test_capturable_adam_follows_a_tensor_that_changes_its_size():
+    """capturable mode keeps one device step counter per 256-element workgroup, laid out by the tensors' sizes.  A group's
+    tensor replaced by a LARGER one (the cat_params_to_optimizer pattern of external.py) used to write counters out of bounds and to
+    shift every later tensor's.  Now the array is re-laid-out (every tensor keeps its count) and the C ABI checks its length:
+    three steps, a resize, three more steps == the same on the host-counted optimiser, bit for bit."""
+    import ctypes as C
+    from topo4d_amd import _lib
+    from topo4d_amd.optim import FusedAdamPins
+    g = torch.Generator().manual_seed(3)
+    shapes = {'a': (700, 3), 'b': (300, 4), 'c': (1000, 1)}
+    lrs = {'a': 1e-3, 'b': 2e-3, 'c': 5e-4}
+    init = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+    extra = torch.randn(900, 3, generator=g)
+    grads = [{k: torch.randn(*(s if not (it >= 3 and k == 'a') else (1600, 3)), generator=g) for k, s in shapes.items()} for it in range(6)]
+    res = []
+    for capturable in (True, False):
+        p = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in init.items()}
+        opt = FusedAdamPins(_groups(p, lrs), eps=1e-15, capturable=capturable)
+        for it in range(6):
+            if it == 3:                                            # cat_params_to_optimizer: a new, larger tensor with extended moments
+                old = p['a']
+                new = torch.nn.Parameter(torch.cat([old.detach(), extra.cuda()], 0))
+                st = opt.state.pop(old)
+                st["exp_avg"] = torch.cat([st["exp_avg"], torch.zeros(900, 3, device="cuda")], 0)
+                st["exp_avg_sq"] = torch.cat([st["exp_avg_sq"], torch.zeros(900, 3, device="cuda")], 0)
+                opt.state[new] = st
+                opt.param_groups[0]["params"] = [new]
+                p['a'] = new
+            for k in p:
+                if not (k == 'c' and it == 1):                     # a tensor that skips a step keeps its own count
+                    p[k].grad = grads[it][k].cuda()
+            opt.step(); opt.zero_grad(set_to_none=True)
+        res.append(({k: v.detach().clone() for k, v in p.items()}, opt.steps()))
+    (pc, sc), (ph, sh) = res
+    assert sc == sh == [6, 6, 5]
+    for k in pc:
+        assert torch.equal(pc[k], ph[k]), (k, (pc[k] - ph[k]).abs().max())
+    # the ABI refuses a counter array of another layout outright
+    lib = _lib.load()
+    t = torch.zeros(512, 3, device="cuda")
+    arr = (_lib.T4DAdamTensor * 1)(_lib.T4DAdamTensor(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, None, 512, 3, 1e-3, 1, 0))
+    cnt = torch.zeros(6, dtype=torch.int32, device="cuda"); lr = torch.zeros(1, device="cuda")
+    assert lib.t4d_adam_step_counters(arr, 1) == 6
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.t4d_adam_pin_step_graph(arr, 1, 0.9, 0.999, 1e-15, cnt.data_ptr(), 5, lr.data_ptr(), stream) == _lib.T4D_ERR_ARG
+    assert lib.t4d_adam_pin_step_graph(arr, 1, 0.9, 0.999, 1e-15, cnt.data_ptr(), 6, lr.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+
+
 def test_per_view_loop_fused_vs_torch_pieces():
     import topo4d_amd
     from tests import util

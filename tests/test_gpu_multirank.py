@@ -136,7 +136,7 @@ def test_view_sharded_two_rank_dry_run_equals_the_24_view_launch():
                  "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--allreduce-grads"] + common,
                 dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", T4D_DIST_BACKEND="nccl", T4D_BENCH_DUMP_LOSSES="2", T4D_FORCE_COLLECTIVES="1"))
     assert rccl["dist_backend"] == "nccl" and "all-reduced" in rccl["config"]["parallelism"]
-    np.testing.assert_array_equal(np.asarray(rccl["gathered_losses_first_steps"], np.float32), l1)
+    np.testing.assert_array_equal(np.asarray(rccl["gathered_losses_first_steps"], np.float32), l1[:2])
 
 
 def test_strong_scaling_rounds_the_job_up_to_whole_steps_per_rank():

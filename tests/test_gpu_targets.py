@@ -366,6 +366,68 @@ def test_graphed_views_on_the_masked_branch_and_the_texture_loop():
         loop.GraphedViews(_dense_params(dense), dataset, FusedAdamPins(_groups(_dense_params(dense), dlrs), capturable=True), dense=True)
 
 
+def test_graphed_texture_loop_follows_update_dense_states_into_the_next_frame():
+    """the reference RE-BINDS variables['dense_init_colors'] and params['dense_means3D'] to new tensors in every later frame
+    (update_dense_states, train.py:498-507) while a recorded iteration reads the storage they had at capture time.  A replay
+    with a re-bound entry is refused; load_frame copies the new contents into the recorded buffers (and binds the entries back):
+    two frames of graphed texture iterations == the same two frames chained by hand, bit for bit."""
+    import topo4d_amd
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    H, W, V = 96, 128, 3
+    dense, init, dataset, dlrs, frozen = _dense_case(H, W, V)
+    g = torch.Generator().manual_seed(77)
+    dataset2 = [dict(e, im=torch.rand(3, H, W, generator=g).cuda()) for e in dataset]
+    shift = (torch.randn(dense['dense_means3D'].shape, generator=g) * 0.001).cuda()
+    schedule = [0, 2, 1, 1]
+
+    def update_dense_states(params, variables):             # what train.py:498-507 does to the two dict entries: NEW tensors
+        variables['dense_init_colors'] = params['dense_rgb_colors'].clone().detach()
+        params['dense_means3D'] = (params['dense_means3D'].detach() + shift).clone()
+
+    def run(graphed):
+        params = _dense_params(dense)
+        variables = {'dense_init_colors': init.clone().cuda()}
+        opt = FusedAdamPins(_groups(params, dlrs), eps=1e-15, capturable=graphed)
+        opt.set_pin('dense_rgb_colors', frozen, 0.0)
+        losses = []
+        if graphed:
+            gv = loop.GraphedViews(params, dataset, opt, dense=True, variables=variables)
+        topo4d_amd.set_sync_mode("lazy")
+        try:
+            for t, data in enumerate((dataset, dataset2)):
+                if t:
+                    update_dense_states(params, variables)
+                    if graphed:
+                        with pytest.raises(RuntimeError, match="load_frame"):
+                            gv.step(0)
+                        gv.load_frame(data)
+                        assert variables['dense_init_colors'].data_ptr() == gv._rebound[0][2].data_ptr()
+                for c in schedule:
+                    if graphed:
+                        losses.append(gv.step(c).clone())
+                    else:
+                        opt.apply_pins(('dense_rgb_colors',))
+                        l, _, grads, _, _ = loop.explicit_iteration(params, data[c], dense=True, soft_color=(variables['dense_init_colors'], 0.02))
+                        for k, gr in grads.items():
+                            params[k].grad = gr
+                        opt.step(pins=False); opt.zero_grad(set_to_none=True)
+                        losses.append(l.clone())
+            if graphed:
+                gv.check()
+        finally:
+            topo4d_amd.set_sync_mode("checked")
+        return {k: v.detach().clone() for k, v in params.items()}, torch.stack(losses), variables['dense_init_colors'].clone()
+
+    pg, lg, ig = run(True)
+    pe, le, ie = run(False)
+    assert torch.equal(lg, le), (lg, le)
+    assert torch.equal(ig, ie) and not torch.equal(ie, init.cuda())
+    for k in pg:
+        assert torch.equal(pg[k], pe[k]), (k, (pg[k] - pe[k]).abs().max())
+    assert not torch.equal(lg[:4], lg[4:])
+
+
 def test_texture_iteration_at_the_texture_pass_size():
     """HOT LOOP 2 at its real size: P = 10^6 dense Gaussians, one 4096 x 3008 view (helpers.py:608-609, README "4K images"): two
     iterations of loop.optimise_dense_views chained by hand == through autograd bit for bit; nothing overflows (the soft-colour

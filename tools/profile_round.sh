@@ -10,6 +10,8 @@ tools/prof.sh ${R}_c2b --opacity B > /dev/null 2>&1
 tools/prof.sh ${R}_c4 --config C4 > /dev/null 2>&1
 PROF_CMD="python $ROOT/tools/big_case.py" tools/prof.sh ${R}_dense > /dev/null 2>&1
 PROF_CMD="python $ROOT/tools/prof_single_view.py" tools/prof.sh ${R}_single_view > /dev/null 2>&1
+PROF_CMD="python $ROOT/tools/prof_dense_1v.py 12" tools/prof.sh ${R}_dense_1v > /dev/null 2>&1      # bench.py's dense_1m: ONE view per call (long-tile kernels)
+PROF_CMD="python $ROOT/tools/prof_dense_1v.py 4" tools/prof.sh ${R}_dense_1v_cam4 > /dev/null 2>&1
 PROF_CMD="python $ROOT/tools/loss_prof.py" tools/prof.sh ${R}_loss > /dev/null 2>&1                  # fused photometric loss, 24 x 512^2
 ( export TMPDIR=/tmp; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_gi -o t -- python $ROOT/tools/prof_graphed_iteration.py > /dev/null 2>&1; cp /tmp/${R}_gi/t_kernel_stats.csv $ROOT/gpurun_out/${R}_graphed_iteration_kernel_stats.csv )   # the launches of one replayed iteration
 python tools/sweep_loss_kernels.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_loss_sweep.txt
@@ -22,6 +24,7 @@ python tools/merge_counters.py gpurun_out/${R}_c2b C2_B > /dev/null
 python tools/merge_counters.py gpurun_out/${R}_c4 C4 > /dev/null
 python tools/merge_counters.py gpurun_out/${R}_dense DENSE_1M > /dev/null
 python tools/merge_counters.py gpurun_out/${R}_single_view SINGLE_VIEW > /dev/null
+python tools/merge_counters.py gpurun_out/${R}_dense_1v DENSE_1M_1V > /dev/null
 cp profiles/traffic.json profiles/valu.json profiles/lanes.json gpurun_out/ 2>/dev/null
 tools/side_benches.sh ${R}_side > /dev/null 2>&1
 python tools/small_launch.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_small_launch.txt      # 1-8 views per call, every build switch

@@ -6,10 +6,12 @@ raw, out = sys.argv[1], sys.argv[2]
 
 import re
 
-def short(n):
-    m = re.search(r"(k_[a-z_0-9]+)", n)
+def short(n, templ=False):
+    """k_name, or (templ) k_name<template arguments> - the instantiations of one kernel are different programs (k_render_bwd whole
+    tiles / long-tile segments, k_fwd_long_seg<0|1>): the text summaries keep them apart."""
+    m = re.search(r"(k_[a-z_0-9]+)(<[^()]*>)?", n)
     if m:
-        return m.group(1)
+        return m.group(1) + ((m.group(2) or "").replace(" ", "").replace("(anonymousnamespace)::", "") if templ else "")
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = n.split("(")[0].split("<")[0]
     return n.split("::")[-1].strip() or "?"
@@ -21,7 +23,7 @@ for f in glob.glob(os.path.join(raw, "trace", "**", "*kernel_stats.csv"), recurs
         o.write("# rocprofv3 --kernel-trace --stats summary (times in ns)\n")
         o.write(f"{'kernel':60s} {'calls':>7s} {'total_ns':>14s} {'avg_ns':>12s} {'pct':>7s} {'min_ns':>10s} {'max_ns':>10s}\n")
         for r in rows:
-            o.write(f"{short(r['Name'])[:60]:60s} {r['Calls']:>7s} {r['TotalDurationNs']:>14s} {float(r['AverageNs']):12.1f} "
+            o.write(f"{short(r['Name'], True)[:60]:60s} {r['Calls']:>7s} {r['TotalDurationNs']:>14s} {float(r['AverageNs']):12.1f} "
                     f"{float(r['Percentage']):7.2f} {r['MinNs']:>10s} {r['MaxNs']:>10s}\n")
     print(open(os.path.join(out, "kernel_stats.txt")).read())
 
@@ -39,7 +41,7 @@ for f in glob.glob(os.path.join(raw, "trace", "**", "*kernel_trace.csv"), recurs
             for r in rows[a:b + 1]:
                 st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
                 gap = 0.0 if prev_end is None else (st - prev_end) / 1e3
-                o.write(f"{short(r['Kernel_Name'])[:40]:40s} {(st - t0) / 1e3:10.1f} {(en - st) / 1e3:10.1f} {gap:8.1f}\n")
+                o.write(f"{short(r['Kernel_Name'], True)[:40]:40s} {(st - t0) / 1e3:10.1f} {(en - st) / 1e3:10.1f} {gap:8.1f}\n")
                 prev_end = en
         print(open(os.path.join(out, "step_timeline.txt")).read())
 
@@ -50,7 +52,7 @@ for p in sorted(glob.glob(os.path.join(raw, "pmc*"))):
         acc = defaultdict(lambda: defaultdict(float))
         cnt = defaultdict(lambda: defaultdict(int))
         for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
+            k = short(r["Kernel_Name"], True)
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
         for k in acc:
@@ -69,11 +71,16 @@ print(open(os.path.join(out, "pmc_summary.txt")).read())
 
 # compact per-kernel counters for bench.py: HBM-side traffic (bytes per launch) and the vector-ALU picture
 # (tools/merge_counters.py copies them into profiles/traffic.json and profiles/valu.json under a config name)
+# (per kernel NAME: the instantiations of a name that run in one step - a dense one-view launch runs k_render_bwd twice, whole tiles
+# and long-tile segments - are summed, weighted by how often each ran relative to the most frequent one)
 def _avg(k, c):
-    v = summary.get(k, {}).get(c)
-    return None if v is None else v["avg_per_launch"]
+    insts = [(n, v[c]) for n, v in summary.items() if n.split("<")[0] == k and c in v]
+    if not insts:
+        return None
+    most = max(v["launches"] for _, v in insts)
+    return sum(v["avg_per_launch"] * v["launches"] / most for _, v in insts)
 counters = {"traffic": {}, "valu": {}}
-for k in summary:
+for k in sorted({n.split("<")[0] for n in summary}):
     if not k.startswith("k_"):
         continue
     f, w = _avg(k, "FETCH_SIZE"), _avg(k, "WRITE_SIZE")

@@ -154,8 +154,8 @@ def load():
     lib.t4d_adam_step_counters.restype = C.c_int64
     lib.t4d_adam_step_counters.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32]
     lib.t4d_adam_pin_step_graph.restype = C.c_int
-    lib.t4d_adam_pin_step_graph.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
-                                            C.c_void_p]
+    lib.t4d_adam_pin_step_graph.argtypes = [C.POINTER(T4DAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p]
     lib.t4d_dense_interpolate.restype = C.c_int
     lib.t4d_dense_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                           C.c_void_p, C.c_void_p]

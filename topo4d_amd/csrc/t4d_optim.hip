@@ -134,9 +134,13 @@ T4D_EXPORT int64_t t4d_adam_step_counters(const T4DAdamTensor *tensors, int32_t 
 }
 
 T4D_EXPORT int t4d_adam_pin_step_graph(const T4DAdamTensor *tensors, int32_t n_tensors, float beta1, float beta2, float eps,
-                                       int32_t *step_dev, const float *lr_dev, void *hip_stream)
+                                       int32_t *step_dev, int64_t n_step_counters, const float *lr_dev, void *hip_stream)
 {
     if (!step_dev || !lr_dev) return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step_graph: step_dev and lr_dev are required%s", "");
+    // the launch writes one counter per workgroup: an array sized for other shapes (a tensor replaced by a larger one) would be
+    // written out of bounds, and every later tensor would read another tensor's counters
+    if (n_step_counters != t4d_adam_step_counters(tensors, n_tensors))
+        return t4d_internal_fail(T4D_ERR_ARG, "t4d_adam_pin_step_graph: n_step_counters does not match t4d_adam_step_counters() of these tensors%s", "");
     return adam_launch(tensors, n_tensors, beta1, beta2, eps, step_dev, lr_dev, hip_stream);
 }
 

@@ -106,9 +106,12 @@ static_assert((kSegLongMin & (kSegLongMin - 1)) == 0, "k_fwd_long_prefix stops a
 thread_local char g_err[512] = "";
 
 // optional per-kernel timing with HIP events (t4d_profile_begin/end); used by bench.py for the roofline object
-enum KernelId { K_PREPROCESS = 0, K_SCAN_TILES, K_SCATTER, K_SORT_TILES, K_RENDER_FWD, K_RENDER_BWD, K_PREPROCESS_BWD, K_COUNT };
+// (the last three only run for launches that may hold long tile lists - a dense pass: the chunk sort + merge of bins beyond the LDS
+// sort buffer, the three depth-parallel forward launches and the segmented backward of a big one-view launch's long tiles)
+enum KernelId { K_PREPROCESS = 0, K_SCAN_TILES, K_SCATTER, K_SORT_TILES, K_RENDER_FWD, K_RENDER_BWD, K_PREPROCESS_BWD,
+                K_SORT_LONG, K_FWD_LONG, K_RENDER_BWD_LONG, K_COUNT };
 const char *const kKernelNames[K_COUNT] = { "k_preprocess", "k_scan_tiles", "k_scatter", "k_sort_tiles", "k_render_fwd",
-                                            "k_render_bwd", "k_preprocess_bwd" };
+                                            "k_render_bwd", "k_preprocess_bwd", "k_sort_long", "k_fwd_long", "k_render_bwd_long" };
 struct ProfRec { int id; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -759,23 +762,24 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // one-pass ranking sort (T4D_FLAG_SHORT_BINS): then the render workgroup of a tile sorts its own bin (no launch at all).
     const bool lat = latency_launch_fwd(kp.T * p.n_views, p.flags);
     kp.fused_sort = (lat && (p.flags & T4D_FLAG_SHORT_BINS) != 0 && getenv("T4D_NO_FUSED_SORT") == nullptr) ? 1u : 0u;
-    if (!kp.fused_sort || kp.long_bins_elsewhere) {
+    if (!kp.fused_sort) {
         ProfScope ps_(stream, K_SORT_TILES);
         // (1024 threads per bin only pay when some bin is long: with the caller's word that every bin fits the ranking sort, a
         // small launch of several views keeps the 256-thread kernel - 4 views of Topo4D's size: 9.7 against 12.6 us)
-        if (kp.fused_sort) {
-        } else if (seg_mode(p) == 1 && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
+        if (seg_mode(p) == 1 && (p.flags & T4D_FLAG_SHORT_BINS) == 0 && getenv("T4D_SORT_256") == nullptr)
             hipLaunchKernelGGL(k_sort_tiles<kLongBlock>, dim3(min(kp.T * p.n_views, 4 * device_cus())), dim3(kLongBlock), 0, stream, kp);
         else
             hipLaunchKernelGGL(k_sort_tiles<kBlock>, dim3(tile_grid(kp.T * p.n_views, 5, 2)), dim3(kBlock), 0, stream, kp);
-        // bins beyond the LDS sort buffer (the caller has not said that there are none): their chunks, then the merges
-        if (kp.long_bins_elsewhere) {
-            hipLaunchKernelGGL(k_sort_long_chunks, dim3(min(kp.T * p.n_views, 2 * device_cus())), dim3(kLongBlock), 0, stream, kp);
-            hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
-        }
     }
     T4D_LAUNCH_CHECK("k_sort_tiles");
-    { ProfScope ps_(stream, K_RENDER_FWD);
+    // bins beyond the LDS sort buffer (the caller has not said that there are none): their chunks, then the merges
+    if (kp.long_bins_elsewhere) {
+        ProfScope ps_(stream, K_SORT_LONG);
+        hipLaunchKernelGGL(k_sort_long_chunks, dim3(min(kp.T * p.n_views, 2 * device_cus())), dim3(kLongBlock), 0, stream, kp);
+        hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
+    }
+    T4D_LAUNCH_CHECK("k_sort_long");
+    {
     kp.tile_blocks = (uint32_t)(lat ? kp.T * p.n_views : tile_grid(kp.T * p.n_views, 6, 2));
     kp.fill_blocks = (uint32_t)(kp.gy * p.n_views);
     kp.fill_vec = (p.W % 4 == 0 && (((uintptr_t)io->out_color | (uintptr_t)io->out_depth | (uintptr_t)io->out_alpha) & 15u) == 0) ? 1u : 0u;
@@ -788,8 +792,11 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // slot table, t4d_raster_render_fwd_long.h); the others through the throughput build, which leaves the long ones out
     const bool long_fwd = seg && seg_mode(p) == 2 && !lat && getenv("T4D_NO_LONG_FWD") == nullptr;
     if (long_fwd) {
+        { ProfScope ps_(stream, K_RENDER_FWD);
         hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, true, true>), fgrid, dim3(kBlock), 0, stream, kp);
+        }
         T4D_LAUNCH_CHECK("k_render_fwd");
+        ProfScope psl_(stream, K_FWD_LONG);
         KP kl = kp;
         kl.tile_blocks = min(kp.slots_per_view, (uint32_t)(8 * device_cus()));
         hipLaunchKernelGGL(k_fwd_long_seg<false>, dim3(kl.tile_blocks), dim3(kBlock), 0, stream, kl);
@@ -797,7 +804,9 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         hipLaunchKernelGGL(k_fwd_long_prefix, dim3(min((uint32_t)kp.T, (uint32_t)(4 * device_cus()))), dim3(kBlock), 0, stream, kl);
         T4D_LAUNCH_CHECK("k_fwd_long_prefix");
         hipLaunchKernelGGL(k_fwd_long_seg<true>, dim3(kl.tile_blocks), dim3(kBlock), 0, stream, kl);
-    } else if (lat) {
+    } else {
+    ProfScope ps_(stream, K_RENDER_FWD);
+    if (lat) {
         if (seg_one) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSegOne, true>), fgrid, dim3(kBlock), 0, stream, kp);
         else if (seg) hipLaunchKernelGGL((k_render_fwd<true, kBlock, kSeg, true>), fgrid, dim3(kBlock), 0, stream, kp);
         else hipLaunchKernelGGL((k_render_fwd<true, kBlock, 0, true>), fgrid, dim3(kBlock), 0, stream, kp);
@@ -810,6 +819,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
         hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, true>), fgrid, dim3(kBlock), 0, stream, kp);
     } else {
         hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, false>), fgrid, dim3(kBlock), 0, stream, kp);
+    }
     }
     }
     T4D_LAUNCH_CHECK("k_render_fwd");
@@ -857,7 +867,7 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     kp.dL_dshs = io->dL_dshs; kp.dL_dopacities = io->dL_dopacities; kp.dL_dscales = io->dL_dscales;
     kp.dL_drotations = io->dL_drotations; kp.dL_dcov3D = io->dL_dcov3D;
 
-    { ProfScope ps_(stream, K_RENDER_BWD);
+    {
     const bool da = kp.dL_ddepth || kp.dL_dalpha;
     const bool lat = latency_launch(kp.T * p.n_views);
     // small launches: one workgroup per segment slot (kSeg; T4D_NO_SEGMENTS=1: whole tiles, for tests and experiments - the
@@ -874,14 +884,19 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
         // two launches: the whole-tile throughput build leaves out the tiles that own segments (the forward wrote their slot-table
         // entries), then the segmented build walks the slot table with a fixed number of workgroups (most of its cap / kSeg + T
         // slots are empty: one workgroup per slot would be 79,000 launches for a few thousand segments)
+        { ProfScope ps_(stream, K_RENDER_BWD);
         if (da) hipLaunchKernelGGL((k_render_bwd<true, false, 0, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
         else hipLaunchKernelGGL((k_render_bwd<false, false, 0, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
+        }
         T4D_LAUNCH_CHECK("k_render_bwd");
+        ProfScope psl_(stream, K_RENDER_BWD_LONG);
         kp.tile_blocks = min(kp.slots_per_view, (uint32_t)(8 * device_cus()));
         grid = kp.tile_blocks;
         if (da) hipLaunchKernelGGL((k_render_bwd<true, false, kSeg, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
         else hipLaunchKernelGGL((k_render_bwd<false, false, kSeg, true>), dim3(grid), dim3(kBlock), 0, stream, kp);
-    } else if (seg && seg_positions(p) == kSegOne) {
+    } else {
+    ProfScope ps_(stream, K_RENDER_BWD);
+    if (seg && seg_positions(p) == kSegOne) {
         if (da) T4D_BWD_LAUNCH(true, false, kSegOne); else T4D_BWD_LAUNCH(false, false, kSegOne);
     } else if (seg) {
         // Segments always run the throughput build: the latency build's one slab per DPP row is 82 KiB of LDS, ONE workgroup per
@@ -890,6 +905,7 @@ T4D_EXPORT int t4d_rasterize_backward(const T4DProblem *prob, const T4DBackwardI
     } else {
         if (lat) { if (da) T4D_BWD_LAUNCH(true, true, 0); else T4D_BWD_LAUNCH(false, true, 0); }
         else { if (da) T4D_BWD_LAUNCH(true, false, 0); else T4D_BWD_LAUNCH(false, false, 0); }
+    }
     }
 #undef T4D_BWD_LAUNCH
     }

@@ -417,9 +417,14 @@ class GraphedViews:
             loss = gv.step(curr_index)                     # device scalar of that iteration (no synchronisation)
         gv.check()                                         # once in a while: raises if a replay outgrew its pair arena
         gv.load_frame(next_dataset)                        # next frame: new target images into the recorded buffers
+                                                           # (dense=True: ALSO the re-bound dense_init_colors / dense_means3D, below)
 
     `use_mask` / `is_initial_timestep` / `label_colors`: get_loss's branch, as optimise_views.  `dense=True` (with `variables`)
     records the texture loop's iteration instead (pins before the render, dense parameters, no affine, soft colour).
+    The recorded kernels read `variables['dense_init_colors']` and `params['dense_means3D']` through the pointers they had at
+    capture time, and the reference RE-BINDS both to new tensors in every later frame (update_dense_states, train.py:498-507).
+    `load_frame` therefore copies whatever the two dict entries hold now INTO the recorded buffers and binds the entries back to
+    them; `step` refuses to replay while an entry points elsewhere (call load_frame after update_dense_states).
     Parameters, optimiser state and pins are the caller's tensors (updated in place by the replays); `opt.param_groups[i]
     ['lr']` may be changed between steps (helpers.update_optimizer does) - step() pushes it to the device copy.
     Replays are un-synchronised like the rasterizer's "lazy" mode: the arena learned during warm-up has 1.5x head-room;
@@ -457,6 +462,9 @@ class GraphedViews:
         self.graphs, self._status_host = [], None
         # the targets the recorded loss kernels read: own buffers, so that load_frame() can bring in the next frame's images
         self._targets = [target_image(e, *self._branch).float().contiguous().clone() for e in dataset]
+        # dense: the two non-parameter inputs of the recorded iteration, (dict, key, the tensor whose storage the graphs read)
+        self._rebound = [(variables, 'dense_init_colors', variables['dense_init_colors']),
+                         (params, 'dense_means3D', params['dense_means3D'])] if dense else []
         try:
             if self.explicit and not dense:
                 self._cam_grads = _adopt_cam_grads(params, optimizer)
@@ -588,10 +596,24 @@ class GraphedViews:
         for buf, e in zip(self._targets, dataset):
             buf.copy_(target_image(e, use_mask, initial, colors))
         self.dataset = dataset
+        # dense: update_dense_states (train.py:498-507) bound NEW tensors to these entries; the graphs read the old storage
+        for d, key, recorded in self._rebound:
+            cur = d[key]
+            if cur is not recorded and cur.data_ptr() != recorded.data_ptr():
+                if cur.shape != recorded.shape:
+                    raise ValueError(f"load_frame: {key} changed its shape ({tuple(cur.shape)} vs the recorded {tuple(recorded.shape)}); "
+                                     "build a new GraphedViews")
+                with torch.no_grad():
+                    recorded.copy_(cur)
+            d[key] = recorded
 
     def step(self, index: int) -> torch.Tensor:
         """Replay the iteration of camera `index`; returns its loss (a device scalar that the next replay of the same camera
         overwrites)."""
+        for d, key, recorded in self._rebound:
+            if d[key].data_ptr() != recorded.data_ptr():
+                raise RuntimeError(f"GraphedViews(dense=True): {key} was re-bound to a new tensor (update_dense_states, train.py:498-507) but the "
+                                   "recorded iteration reads the old one: call load_frame(dataset) after update_dense_states")
         self.opt.sync_hyper()
         self.graphs[index].replay()
         return self.losses[index]

@@ -40,6 +40,7 @@ class FusedAdamPins:
         # iteration fills only in part (loop.GraphedViews: the per-camera rows of cam_m / cam_c)
         self.clear_grad: set = set()
         self._step_dev: Optional[torch.Tensor] = None
+        self._layout = None                 # (first counter of every tensor, their number) the counter array was built for
         self._lr_dev: Optional[torch.Tensor] = None
         self._lr_host: Optional[List[float]] = None
 
@@ -53,10 +54,28 @@ class FusedAdamPins:
         return first, n
 
     def _hyper(self, dev):
+        """(step counters, learning rates) on the device.  The counters are laid out by the tensors' CURRENT sizes (one per
+        workgroup of 256 elements); when a group's tensor has been replaced by one of another size (the cat_params_to_optimizer /
+        remove_points pattern of external.py) the array is rebuilt, every tensor keeping its count - inside a stream capture that is
+        impossible (the recorded launches hold the old pointer): then it raises."""
+        first, n = self._counter_layout()
         if self._step_dev is None:
-            _, n = self._counter_layout()
             self._step_dev = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
             self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+            self._layout = (first, n)
+        elif self._layout != (first, n):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdamPins(capturable=True): a parameter changed its size; the recorded steps hold the old "
+                                   "counter array - build new graphs")
+            old_first, old_n = self._layout
+            new = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+            for k, f in enumerate(first):
+                cnt = (first[k + 1] if k + 1 < len(first) else n) - f
+                had = (old_first[k + 1] if k + 1 < len(old_first) else old_n) - old_first[k]
+                if cnt > 0 and had > 0:
+                    new[f:f + cnt] = self._step_dev[old_first[k]]          # all counters of a tensor are equal: any of them
+            self._step_dev = new
+            self._layout = (first, n)
         return self._step_dev, self._lr_dev
 
     def sync_hyper(self) -> None:
@@ -72,7 +91,8 @@ class FusedAdamPins:
     def steps(self) -> List[int]:
         """Per-tensor step counts (synchronising read in capturable mode)."""
         if self.capturable and self._step_dev is not None:
-            first, _ = self._counter_layout()
+            self._hyper(self._step_dev.device)              # (re-laid-out first if a tensor changed its size)
+            first, _ = self._layout
             host = self._step_dev.tolist()
             return [int(host[f]) if g["params"][0].numel() > 0 else 0 for f, g in zip(first, self.param_groups)]
         return [int(self.state.get(g["params"][0], {}).get("step", 0)) for g in self.param_groups]
@@ -196,7 +216,7 @@ class FusedAdamPins:
                 self.sync_hyper()
             step_dev, lr_dev = self._hyper(dev)
             rc = lib.t4d_adam_pin_step_graph(arr, len(self.param_groups), float(self.betas[0]), float(self.betas[1]),
-                                             float(self.eps), C.c_void_p(step_dev.data_ptr()), C.c_void_p(lr_dev.data_ptr()), stream)
+                                             float(self.eps), C.c_void_p(step_dev.data_ptr()), self._layout[1], C.c_void_p(lr_dev.data_ptr()), stream)
         else:
             rc = lib.t4d_adam_pin_step(arr, len(self.param_groups), float(self.betas[0]), float(self.betas[1]),
                                        float(self.eps), stream)
