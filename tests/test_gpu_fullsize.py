@@ -323,16 +323,40 @@ def test_auto_sync_mode_tracks_capacity_without_syncing():
         for a, b in zip(out, chk):
             assert torch.equal(a, b)
         # an abrupt jump (scales x6 from one call to the next) overflows once: the truncated render's OWN backward raises, before
-        # any gradient exists and before an optimiser could step (it used to return zero gradients and raise one call later)
+        # any gradient exists and before an optimiser could step - whenever its binning status has landed by then (it was copied
+        # out right behind the binning kernels; here the device is drained first, in a loop the loss sits in between)
         rasterizer._forget_scenes()
         call(R[0]); call(R[0])
         leaf = d["means3D"].clone().requires_grad_(True)
         out_t = R[0](leaf, None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * 6.0, rotations=d["rotations"])
+        torch.cuda.synchronize()
         with pytest.raises(RuntimeError, match="truncated"):
             out_t[0].sum().backward()
         assert leaf.grad is None
         assert not rasterizer._PENDING                         # ... and the books are clean: nothing left to report later
         topo4d_amd.poll_truncation()
+        # ... and when the status has NOT landed yet (a host running ahead of the device; forced here): the backward does not wait -
+        # it launches, the library writes ZERO gradients for the truncated forward, and the truncation raises at the next look:
+        # before the fused optimiser's step, or in poll_truncation() / the next forward.  Never a non-zero gradient, never a wait.
+        from topo4d_amd.optim import FusedAdamPins
+        rasterizer._forget_scenes()
+        call(R[0]); call(R[0])
+        leaf = torch.nn.Parameter(d["means3D"].clone())
+        opt = FusedAdamPins([{'params': [leaf], 'name': 'means3D', 'lr': 1e-3}])
+        before = leaf.detach().clone()
+        out_t = R[0](leaf, None, d["opacities"], colors_precomp=d["colors_precomp"], scales=d["scales"] * 6.0, rotations=d["rotations"])
+        real_landed = rasterizer._Pending.landed
+        rasterizer._Pending.landed = lambda self: False
+        try:
+            out_t[0].sum().backward()                          # no exception, no wait
+        finally:
+            rasterizer._Pending.landed = real_landed
+        assert leaf.grad is not None and not leaf.grad.any()   # zeros, written by the library itself
+        assert len(rasterizer._PENDING) == 1
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="truncated"):
+            opt.step()                                         # the look before the step
+        assert torch.equal(leaf.detach(), before) and not rasterizer._PENDING
         out = call(R[0], 6.0)                                  # arena was enlarged: now complete again
         topo4d_amd.set_sync_mode("checked")
         for a, b in zip(out, call(R[0], 6.0)):

@@ -181,7 +181,6 @@ def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
     assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and "view-sharded x8" in eight["config"]["parallelism"]
     assert eight["config"]["views_per_step_per_gpu"] == 3 and eight["config"]["frames_per_launch"] == 1
     l8 = np.asarray(eight["gathered_losses_first_steps"], np.float32)        # [step, rank-major 8 x 3]
-    l1 = np.asarray(one["gathered_losses_first_steps"], np.float32)          # [step, 24]
     unit_order = l8.reshape(2, 8, 3).transpose(0, 2, 1).reshape(2, 24)
     np.testing.assert_allclose(unit_order, l1, rtol=5e-6, atol=1e-10)
     # the 24 scalars of a frame are all different: a view in the wrong slot would be off by orders of magnitude more

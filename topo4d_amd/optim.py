@@ -182,6 +182,11 @@ class FusedAdamPins:
     def step(self, pins: bool = True) -> None:
         """Adam for every tensor that has a gradient, then (pins=True) the pinned rows of every tensor - one launch."""
         lib = _lib.load()
+        from . import rasterizer
+        if rasterizer._PENDING and not torch.cuda.is_current_stream_capturing():
+            # "auto" sync mode of the rasterizer: a render whose pair arena overflowed raises HERE at the latest, before the step
+            # (its backward carried zero gradients); nothing pending: one truth test of a deque
+            rasterizer.poll_truncation()
         arr = (_lib.T4DAdamTensor * len(self.param_groups))()
         keep = []
         dev = None

@@ -202,8 +202,9 @@ def _truncation_error(truncated) -> RuntimeError:
 def poll_truncation(wait_for: Optional["_Pending"] = None, _after_sync: bool = False, _synced_device=None) -> None:
     """"auto" sync mode: look at every binning status that has landed since the last look - of ALL camera sets, not only
     the one being rendered - grow the arenas they ask for, and raise RuntimeError if any of those forwards was truncated.
-    Every auto-mode forward calls this first, and every auto-mode BACKWARD calls it for its own forward (`wait_for`, below) before
-    it returns a gradient, so a truncated pass raises inside `loss.backward()` - before `optimizer.step()`.
+    Every auto-mode forward calls this first, every auto-mode BACKWARD calls it for its own forward once that status has landed
+    (`wait_for`, below), and `FusedAdamPins.step()` calls it before it launches, so a truncated pass raises inside
+    `loss.backward()` or, at the latest, before the fused optimiser step (a backward that ran ahead of its status carries zeros).
     Without `wait_for` it never synchronises: statuses are inspected in submission order, the first one still in flight ends
     the look.  With `wait_for` (the entry of one forward) it returns only once THAT status has landed: the copy was enqueued
     behind the forward's binning kernels, long before the loss and the backward were, so it has normally arrived already;
@@ -266,9 +267,11 @@ def set_sync_mode(mode: str) -> None:
     kernels.  The arena is grown as soon as 75 % of it is in use (it is sized 1.5x the largest need seen), so consecutive
     iterations of an optimiser cannot overflow it.  Should a forward nevertheless be truncated (the scene jumped by more than
     a third between two calls), ITS OWN BACKWARD raises RuntimeError before it returns any gradient - `loss.backward()` fails,
-    `optimizer.step()` is never reached with the gradients of an incomplete render - and the arena has been enlarged for the
-    re-run.  (The backward looks at the pinned status words; they have normally landed long before, otherwise it waits for
-    them - not for the stream.)  `poll_truncation()` does the same look on demand."""
+    `optimizer.step()` is never reached - and the arena has been enlarged for the re-run.  The backward LOOKS at the pinned
+    status words and never waits for them: they have normally landed long before (the loss sits between the forward and its
+    backward); if they have not, the backward is launched, the library itself writes ZERO gradients for a truncated forward - no
+    gradient of an incomplete render ever exists - and the RuntimeError comes from the next look: the next auto-mode forward,
+    `FusedAdamPins.step()` (before it launches) or `poll_truncation()`."""
     global _SYNC_MODE, _SYNC_MODE_EXPLICIT
     if mode not in ("checked", "lazy", "auto"):
         raise ValueError("sync mode must be 'checked', 'lazy' or 'auto'")
@@ -664,11 +667,15 @@ class ViewBatch:
         pending = self.pending
         if pending is not None:
             # "auto" mode: no gradient of a truncated render ever leaves this function.  The status was copied out right behind
-            # the forward's binning kernels and is looked at HERE, after the host-side preparation above: normally two host
-            # loads (see poll_truncation); a host that runs ahead of the GPU waits for those two words, not for the stream
-            if not pending.done:
+            # the forward's binning kernels and is LOOKED AT here, after the host-side preparation above - two host loads, never a
+            # wait.  Landed (the normal case: the loss was enqueued in between): a truncated forward raises now, before any gradient
+            # exists.  Not landed yet (a host running ahead of the device): the backward is launched all the same - the library
+            # writes ZERO gradients for a truncated forward (include/topo4d_raster.h) - and the truncation raises at the next look
+            # (every auto-mode forward, FusedAdamPins.step(), poll_truncation()).  Waiting here instead made host and device hand
+            # over to each other once per iteration: two throughput regimes of one build, 4-5 k and 8-9 k it/s (round 5).
+            if not pending.done and pending.landed():
                 poll_truncation(wait_for=pending)
-            if pending.overflow:
+            if pending.done and pending.overflow:
                 raise _truncation_error((pending.need, pending.cap))
         rc = lib.t4d_rasterize_backward(C.byref(prob), plan.bio_ref, _raw_stream(dev))
         if rc != T4D_OK:
