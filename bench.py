@@ -754,7 +754,7 @@ def bake_probe(dev, cpu=True, res=8192, n=1025):
     face3d render_colors -> _render_colors_core, helpers.py:953-960, mesh_core.cpp:169-234) of a UV mesh of ~10^6 vertices /
     2.1 M triangles.  Algorithmic bytes: 16 B per texel (3 colour floats + the depth buffer) + the inputs read once."""
     from oracle import texture_oracle as TX
-    from tests.test_texture_oracle import uv_mesh
+    from scaffold.scene import uv_mesh
     from topo4d_amd import texture
     verts, tris, colors = uv_mesh(n, res, res, seed=0)
     tris = np.sort(tris.view([("a", np.int32), ("b", np.int32), ("c", np.int32)]), order=["a"], axis=0).view(np.int32)   # mesh order

@@ -197,3 +197,21 @@ def make_dense_params(params: Dict[str, torch.Tensor], per_vertex: int = 4, seed
         "dense_unnorm_rotations": torch.tensor([1.0, 0.0, 0.0, 0.0]).repeat(n, 1),
     }
     return dense, dense["dense_rgb_colors"].clone()
+
+
+# ---- UV-space mesh of the texture bake (config 5) ---------------------------------------------------------------------
+def uv_mesh(n, h, w, seed=0, with_depth=False):
+    """A jittered n x n UV grid as a triangle soup in pixel space, triangles shuffled (BASELINE config 5: the synthetic mesh of the
+    texture bake - tests, bench.py and tools/bench_bake.py share it).  Returns (vertices [n*n,3] float32 (x, y, depth), triangles
+    [2(n-1)^2,3] int32, colours [n*n,3] float32)."""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.linspace(0.01, 0.99, n), np.linspace(0.01, 0.99, n), indexing="xy")
+    uv = np.stack([u.ravel(), v.ravel()], 1) + rng.normal(0, 0.2 / n, size=(n * n, 2))
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c_, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c_], 1), np.stack([b, d, c_], 1)]).astype(np.int32)
+    rng.shuffle(tris)
+    z = rng.normal(0, 1, n * n) if with_depth else np.zeros(n * n)
+    verts = np.stack([uv[:, 0] * (w - 1), h - uv[:, 1] * (h - 1) - 1, z], 1).astype(np.float32)
+    colors = rng.uniform(0, 1, size=(n * n, 3)).astype(np.float32)
+    return verts, tris, colors

@@ -231,7 +231,7 @@ def test_dense_envelope_one_million_gaussians_through_the_drop_in():
 # ------------------------------------------------------------------------------------------------------------------
 def test_c5_texture_bake_8192_bit_identical_to_reference_code():
     from oracle import texture_oracle as TX
-    from tests.test_texture_oracle import uv_mesh
+    from scaffold.scene import uv_mesh
     from topo4d_amd import texture
     res, n = 8192, 1025                                   # 1,050,625 vertices, 2,097,152 triangles
     verts, tris, colors = uv_mesh(n, res, res, seed=0)

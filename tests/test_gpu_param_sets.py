@@ -97,24 +97,33 @@ def test_parameter_sets_with_raw_optimiser_parameters_and_cov3d():
     rvs = _frames(n_sets, 16, 24, seed=21)
     _, cams = util.make_scene(4, 4, H, W, n_cams)
     dc, _, _ = scene.output_cotangents(V, H, W, seed=22)
-    act, ag, _ = _render_sets(cams, rvs, dc)
-    raws = []
+    from topo4d_amd.boundary import activate_backward, activate_forward
+    raws, acts = [], []
     for rv in rvs:
         raw = dict(rv)
         raw["rotations"] = rv["rotations"] * torch.linspace(0.5, 2.0, rv["rotations"].shape[0])[:, None]   # un-normalised quaternions
         raw["opacities"] = torch.logit(rv["opacities"].clamp(1e-6, 1 - 1e-6))
         raw["scales"] = torch.log(rv["scales"])
         raws.append(raw)
+        # what the library's own activation kernel makes of them (the arithmetic T4D_FLAG_RAW_PARAMS applies inside the rasterizer)
+        rot, op, sc = activate_forward(raw["rotations"].cuda().contiguous(), raw["opacities"].cuda().contiguous(), raw["scales"].cuda().contiguous())
+        acts.append(dict(rv, rotations=rot.cpu(), opacities=op.cpu(), scales=sc.cpu()))
+    act, ag, _ = _render_sets(cams, acts, dc)
     hip, hg, _ = _render_sets(cams, raws, dc, raw=True)
-    for v in range(V):
-        assert np.abs(hip["color"][v] - act["color"][v]).max() < 2e-5
-        np.testing.assert_array_equal(hip["radii"][v], act["radii"][v])
-    assert np.isfinite(hg["rotations"]).all() and np.abs(hg["scales"]).max() > 0
-    # the raw gradients are the chain rule of the activated ones: d/dlog_scale = scale * d/dscale
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(hip[k], act[k])                 # bit for bit: same activated values, same kernels
+    for k in ("means3D", "means2D", "colors_precomp"):
+        np.testing.assert_array_equal(hg[k], ag[k])
+    # the raw gradients are the activation's vector-Jacobian products of the activated ones, per view
     for s in range(n_sets):
-        sl = slice(s * n_cams, (s + 1) * n_cams)
-        want = ag["scales"][sl] * rvs[s]["scales"].numpy()[None]
-        assert np.abs(hg["scales"][sl] - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30) + 1e-9
+        for c in range(n_cams):
+            v = s * n_cams + c
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            d_rot, d_op, d_sc = activate_backward(raws[s]["rotations"].cuda().contiguous(), acts[s]["opacities"].cuda().contiguous(),
+                                                  acts[s]["scales"].cuda().contiguous(), t(ag["rotations"][v]), t(ag["opacities"][v]), t(ag["scales"][v]))
+            for name, want in (("rotations", d_rot), ("opacities", d_op), ("scales", d_sc)):
+                w = want.cpu().numpy()
+                assert np.abs(hg[name][v] - w).max() <= 2e-6 * max(np.abs(w).max(), 1e-30) + 1e-12, (name, v)
     covs = []
     for rv in rvs:
         R = TO.quat_to_rot(rv["rotations"].double())

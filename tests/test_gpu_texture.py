@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from oracle import texture_oracle as TX
-from tests.test_texture_oracle import G, uv_mesh
+from scaffold.scene import uv_mesh
+from tests.test_texture_oracle import G
 
 pytestmark = pytest.mark.gpu
 

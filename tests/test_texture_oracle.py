@@ -7,22 +7,9 @@ import numpy as np
 import pytest
 
 from oracle import texture_oracle as TX
+from scaffold.scene import uv_mesh
 
 G = os.path.join(os.path.dirname(__file__), "golden", "g5_render_colors.npz")
-
-
-def uv_mesh(n, h, w, seed=0, with_depth=False):
-    rng = np.random.default_rng(seed)
-    u, v = np.meshgrid(np.linspace(0.01, 0.99, n), np.linspace(0.01, 0.99, n), indexing="xy")
-    uv = np.stack([u.ravel(), v.ravel()], 1) + rng.normal(0, 0.2 / n, size=(n * n, 2))
-    idx = np.arange(n * n).reshape(n, n)
-    a, b, c_, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
-    tris = np.concatenate([np.stack([a, b, c_], 1), np.stack([b, d, c_], 1)]).astype(np.int32)
-    rng.shuffle(tris)
-    z = rng.normal(0, 1, n * n) if with_depth else np.zeros(n * n)
-    verts = np.stack([uv[:, 0] * (w - 1), h - uv[:, 1] * (h - 1) - 1, z], 1).astype(np.float32)
-    colors = rng.uniform(0, 1, size=(n * n, 3)).astype(np.float32)
-    return verts, tris, colors
 
 
 def test_port_matches_golden_outputs_of_the_real_reference():

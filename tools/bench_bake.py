@@ -7,7 +7,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import texture_oracle as TX
-from tests.test_texture_oracle import uv_mesh
+from scaffold.scene import uv_mesh
 from topo4d_amd import texture
 
 ap = argparse.ArgumentParser()
