@@ -213,3 +213,19 @@ def test_parsing_colormap_is_the_reference_cmap():
     assert m.shape == (3, 48, 40) and m.dtype == torch.float32
     inner = (torch.abs(m * 255 - torch.tensor(g["label_colors"][8]).reshape(3, 1, 1)) < 1).all(0)
     assert 0 < int(inner.sum()) < 48 * 40 // 4
+
+
+def test_drop_in_import_runs_the_backward_on_the_calling_thread():
+    """Importing `diff_gaussian_rasterization` switches torch's per-device autograd worker thread off (the hand-over per
+    `loss.backward()` made the one-view loop run at 4-5 k OR 8-9 k it/s: profiles/r06_dropin_regimes.txt);
+    T4D_AUTOGRAD_ENGINE_THREAD=1 leaves torch's default alone.  Fresh interpreters: the setting is process-wide."""
+    import subprocess
+    import sys
+    code = "import torch, diff_gaussian_rasterization; print(torch.autograd.is_multithreading_enabled())"
+    env = {k: v for k, v in os.environ.items() if k != "T4D_AUTOGRAD_ENGINE_THREAD"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "False", out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, T4D_AUTOGRAD_ENGINE_THREAD="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "True", out.stdout + out.stderr
