@@ -37,7 +37,7 @@ P = 10^6, 4096x3008; `camera_4`: the same from the camera that sees the scene's 
 iteration of the texture loop, train.py:729-741, at that size), `loss` (the
 fused photometric loss at three shapes with its own roofline), `bake_8192` (BASELINE config 5 with its own roofline and the
 reference's own code timed beside it), `full_iteration` (render + fused loss + Adam/pins), `drop_in` and `sequential` — see
-DESIGN.md §Measurement.
+DESIGN.md §6.
 """
 from __future__ import annotations
 
@@ -635,7 +635,7 @@ def dense_1m_probe(dev, reps=5):
                        "counters": counters_provenance("DENSE_1M_1V")}
     # The same scene from the rig's camera 4, which looks at a polar cap of the lat-long head: hundreds of tiles with lists of
     # 2,000 - 9,000 pairs (camera 12 above: one of 12,614).  Same wave-steps; what differs is how long the longest tiles keep
-    # their workgroups (their backward is cut into depth segments).
+    # their workgroups (HISTORY.md section 5 item 1: their backward is cut into depth segments).
     try:
         b4 = ViewBatch(pack_views(scene.camera_rig(H, W, n_views=24, device=dev)[4:5], dev), H, W)
         f4 = lambda: (b4.forward(rv["means3D"], rv["opacities"], rv["scales"], rv["rotations"], rv["colors_precomp"]), b4.backward(dc))
@@ -1060,7 +1060,7 @@ def main():
         ach = per_kernel[dom] * VL / (kernels[dom]["avg_us"] * 1e-6) / 1e9
         traffic = load_profile_json("traffic.json", args.config, dom)
         # vector-ALU counters of the committed rocprofv3 --pmc passes (tools/prof.sh -> profiles/valu.json): what actually limits
-        # the render kernels.  busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * kernel cycles).
+        # the render kernels (HISTORY.md section 5).  busy = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (SIMDs * kernel cycles).
         valu = load_profile_json("valu.json", args.config, dom)
         # What bounds the dominant kernel, FROM THE COUNTERS: the vector ALUs are "busy" SQ_ACTIVE_INST_VALU x 4 / (SIMDs x kernel
         # cycles) of the time; above 0.6 the kernel is issue-bound and the HBM fraction is low by construction.  `achieved`/`peak`/

@@ -204,7 +204,7 @@ def test_c2_full_size_gradient_identities(c2):
 def test_c2_full_size_all_views_against_c_oracle(c2):
     """BASELINE config 2 at full size, scenario A: EVERY one of the 24 views - radii, pair counts, per-tile counts, last
     contributors, colour / depth / alpha and all gradients - against the C oracle (threads: the oracle calls release the GIL).
-    6.3 M pixels: a view may hold up to two threshold pixels, the launch at most eight; every Gaussian without one
+    6.3 M pixels: a view may hold up to two threshold pixels (HISTORY.md section 2), the launch at most eight; every Gaussian without one
     in reach meets the plain tolerance."""
     from tests.test_gpu_parity import check_view_modulo_flips
     total = 0

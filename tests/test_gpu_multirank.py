@@ -156,7 +156,7 @@ def test_view_sharded_eight_rank_dry_run_equals_the_24_view_launch():
     Gaussians (T4DProblem.views_per_param_set) - 24 views, the launch shape of the one-GPU run: per view the gathered loss scalars
     and rank 0's gradient checksums equal the one-GPU run's BIT FOR BIT.
     --frames-per-launch 1 (one frame at a time, the real loop's schedule): a three-view launch runs the depth-SEGMENTED backward
-    (DESIGN section 5), whose replay starts from the forward's snapshots: its sums - and the per-view scalar <colour, dL/dcolour>
+    (HISTORY.md section 5), whose replay starts from the forward's snapshots: its sums - and the per-view scalar <colour, dL/dcolour>
     the ranks gather, a by-product of that replay - agree with the whole-tile replay of the 24-view launch to summation-order
     rounding.  What IS exact there: every view lands in its slot of the gathered vector."""
     common = ["--steps", "2", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--shard", "views"]

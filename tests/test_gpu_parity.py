@@ -87,7 +87,7 @@ def check_grads_modulo_flips(hip_g, ref_g, v, flips, xy, radii, keys=util.GRAD_K
 
 def check_view_modulo_flips(hip, hip_g, v, r, ref_g, st, max_flips, keys=util.GRAD_KEYS, truth=None):
     """One view of a full-size launch against its C-oracle render `r`: integer state exact; at most `max_flips` THRESHOLD pixels
-    (a discrete decision within round-off of its threshold, `v_exp_f32` vs glibc's expf: DESIGN section 2 - about one scene in forty
+    (a discrete decision within round-off of its threshold, `v_exp_f32` vs glibc's expf: HISTORY.md section 2 - about one scene in forty
     has one), everything else within the plain tolerances.  Returns the number of threshold pixels."""
     np.testing.assert_array_equal(hip["radii"][v], r.radii)
     assert int(st["view_total"][v]) == r.num_rendered

@@ -428,6 +428,35 @@ def test_graphed_texture_loop_follows_update_dense_states_into_the_next_frame():
     assert not torch.equal(lg[:4], lg[4:])
 
 
+def test_texture_loop_pins_must_be_cleared_before_the_next_geometry_loop():
+    """the reference writes the frozen rows of dense_rgb_colors before the texture loop's renders
+    ONLY (train.py:731-734); `optimizer.step()` of the geometry loop applies EVERY registered pin.  With `clear_pin` after the texture
+    loop the next frame's geometry steps leave dense_rgb_colors alone - what update_dense_states (train.py:502) then clones is what the
+    reference clones; without it the rows read zero."""
+    from topo4d_amd import loop
+    from topo4d_amd.optim import FusedAdamPins
+    H, W, V = 64, 64, 2
+    dense, init, dataset, dlrs, frozen = _dense_case(H, W, V)
+    geo = {'means3D': torch.nn.Parameter(torch.randn(50, 3).cuda())}
+    for clear in (True, False):
+        params = _dense_params(dense)
+        allp = dict(params, **geo)
+        opt = FusedAdamPins(_groups(allp, dict(dlrs, means3D=1e-3)), eps=1e-15)
+        variables = {'dense_init_colors': init.clone().cuda()}
+        opt.set_pin('dense_rgb_colors', frozen, 0.0)
+        loop.optimise_dense_views(params, variables, dataset, opt, n_iters=3, seed=0)
+        after_texture = params['dense_rgb_colors'].detach().clone()
+        assert (after_texture[frozen] != 0).any()                    # the pinned rows hold the last step's values, as in the reference
+        if clear:
+            opt.clear_pin('dense_rgb_colors')
+        geo['means3D'].grad = torch.randn(50, 3).cuda()              # a geometry step of the next frame: only means3D has a gradient
+        opt.step(); opt.zero_grad(set_to_none=True)
+        if clear:
+            assert torch.equal(params['dense_rgb_colors'].detach(), after_texture)
+        else:
+            assert not params['dense_rgb_colors'].detach()[frozen].any()
+
+
 def test_texture_iteration_at_the_texture_pass_size():
     """HOT LOOP 2 at its real size: P = 10^6 dense Gaussians, one 4096 x 3008 view (helpers.py:608-609, README "4K images"): two
     iterations of loop.optimise_dense_views chained by hand == through autograd bit for bit; nothing overflows (the soft-colour

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 BATCH = 128                     # kBwdBatch: staged splats per batch
-STEP_BUILT = 55                 # vector instructions per wave-step of the built kernel
+STEP_BUILT = 55                 # vector instructions per wave-step of the built kernel (HISTORY.md section 6.3)
 BATCH_BUILT = 340               # per wave-batch outside the walk (staging, masks, lists, conflict ballots, write-out)
 
 

@@ -1,5 +1,5 @@
 """Soak run of the long-tile path of big one-view launches (one view of more than 8,192 tiles: tiles of at least 2,048 pairs are cut
-into depth segments, in a launch of their own behind the whole-tile backward - DESIGN.md section 5 item 1): random heads with
+into depth segments, in a launch of their own behind the whole-tile backward - HISTORY.md section 5 item 1): random heads with
 random clusters of thin splats, the hybrid backward against the whole-tile replay of everything (T4D_NO_SEGMENTS=1; the forward is
 the same program either way and must be bit-equal), and the long tiles' depth-parallel forward against the one-pass forward
 (T4D_NO_LONG_FWD=1).  GPU box.

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_scatter_small(const KP kp)
 // the barrier between workgroups are the per-tile counts and the slot cursors, both products of RETURNING device-scope atomics
 // (performed at the memory side, complete before their result is used) and read back with agent-scope atomic loads: no fence,
 // no L2 write-back (a __threadfence() per workgroup cost the round-3 experiment 10x its gain).  One launch and one trip
-// through memory less per forward: 9.9 + 7.7 us -> see DESIGN.md section 5.
+// through memory less per forward: 9.9 + 7.7 us -> see HISTORY.md section 5.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

@@ -18,7 +18,7 @@
 //      the stop rule, and finishes those pixels.
 // The sums are associated differently from the one-pass forward's (T_in C_seg against c a T splat by splat: ~1e-7 relative), and a
 // pixel whose transmittance comes within rounding of the threshold at a segment's end may stop one contributing splat earlier or
-// later than the one-pass walk would - the class of the alpha >= 1/255 threshold pixels, weight <= 1e-4.
+// later than the one-pass walk would - the class of the alpha >= 1/255 threshold pixels (HISTORY.md section 2), weight <= 1e-4.
 #pragma once
 
 constexpr uint32_t kStopCode = 0x80000000u;          // n_contrib between launches 2 and 3: kStopCode | the segment the pixel stops in
