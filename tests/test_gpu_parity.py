@@ -240,9 +240,9 @@ def test_ragged_image_and_background(render_build):
 @pytest.mark.parametrize("P,hint", [(5000, "unknown"), (5000, "no-long-bins"), (20000, "unknown")])
 def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch):
     """Thousands of large Gaussians on 4x4 tiles: every bin is longer than one LDS batch (256) and longer than k_sort_tiles'
-    LDS buffer (2048), so the multi-batch blend/replay and the long-bin sort run: k_sort_long in LDS (5,000 keys per bin), its
-    chunk + global-merge path (20,000 keys per bin > 16,384), and - when the host wrongly hinted "no long bins" - the slow
-    in-kernel fallback of k_sort_tiles."""
+    LDS buffer (2048), so the multi-batch blend/replay and the long-bin sort run: k_sort_long_chunks + k_merge_long on bins of 5,000
+    keys (three chunks, one group of siblings) and of 20,000 keys (ten chunks, three groups), and - when the host wrongly hinted
+    "no long bins" - the slow in-kernel fallback of k_sort_tiles."""
     from topo4d_amd import rasterizer
     H = W = 64
     V = 1
@@ -283,7 +283,7 @@ def test_long_tile_lists_and_every_sort_path(P, hint, render_build, monkeypatch)
 
 
 def test_bins_of_exactly_the_lds_sort_capacity_among_more_long_bins_than_cus():
-    """k_sort_long walks the length-ordered work items and leaves bins of <= 2048 keys to k_sort_tiles.  The order is by length
+    """The long-bin kernels (k_sort_long_chunks, k_merge_long) walk the length-ordered work items and leave bins of <= 2048 keys to k_sort_tiles.  The order is by length
     CLASS only (floor(log2 n)), so a bin of exactly 2048 keys can sit in front of longer bins of its class: with more long bins
     than workgroups (one per CU) a workgroup that met such a bin used to stop and leave its later bins unsorted.  350 one-tile
     views of 2100 stacked Gaussians; the near plane cuts 0..52 of them depending on the camera, 150 views keep exactly 2048."""

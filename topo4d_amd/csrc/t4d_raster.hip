@@ -28,8 +28,9 @@
 //   k_scatter         A.2  per (view,Gaussian): key -> tile_off + rank (no atomics); tail blocks build the work items
 //   k_sort_tiles      A.2  per work item: sort the bin by (depth bits, index): runs of 64 sorted in registers, merged by
 //                          ranking (<= 512 keys: one pass; <= 2048: log levels in LDS)
-//   k_sort_long       A.2  bins beyond 2048 keys (dense passes): a CU each - 1024 threads, 128 KiB of LDS for up to 16,384 keys,
-//                          longer ones chunk-sorted and merged in global memory
+//   k_sort_long_chunks, k_merge_long  A.2  bins beyond 2048 keys (dense passes): every 2048-key chunk sorted through LDS by whichever
+//                          workgroup it falls to, then ONE ranking pass (a key's slot = its place in its chunk + the keys below it in
+//                          every other chunk) scatters the keys to their final places - any bin length, chunks in parallel
 //   k_render_fwd      A.3  per work item: 256 threads = 4 wave64 = 16 DPP rows, one 4x4 sub-block each; front-to-back blend;
 //                          empty tiles are written by row-fill workgroups of the same launch (fill_empty_tile_row)
 //   k_render_bwd      A.4  per work item: back-to-front replay, row-local reduction, one record per pair
@@ -62,8 +63,7 @@ constexpr int kFwdBatch = T4D_FWD_BATCH;   // splats staged in LDS per round of 
 #endif
 constexpr int kBwdBatch = T4D_BWD_BATCH;   // splats staged per round of the backward replay (64 or 128)
 constexpr int kSortLdsCap = 2048;    // keys sorted in LDS by k_sort_tiles (16 KiB: 8 workgroups per CU); longer bins go to k_sort_long
-constexpr int kLongBlock = 1024;     // k_sort_long: threads per workgroup ...
-constexpr int kLongCap = 16384;      // ... and keys it sorts in LDS (128 KiB: one workgroup per CU)
+constexpr int kLongBlock = 1024;     // k_sort_long_chunks, k_merge_long (bins beyond kSortLdsCap keys) and small launches' k_sort_tiles: threads per workgroup
 constexpr int kScanChunk = 1024;     // tiles scanned per workgroup of k_scan_tiles
 constexpr int kRankSortMax = 512;    // bins up to this length: register-sorted runs of 64 + one ranking pass (one barrier)
 constexpr int kHist = 1024;          // per-workgroup LDS tile histogram (bounding box of the tiles a workgroup touches)
@@ -776,7 +776,7 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     if (kp.long_bins_elsewhere) {
         ProfScope ps_(stream, K_SORT_LONG);
         hipLaunchKernelGGL(k_sort_long_chunks, dim3(min(kp.T * p.n_views, 2 * device_cus())), dim3(kLongBlock), 0, stream, kp);
-        hipLaunchKernelGGL(k_sort_long, dim3(min(kp.T * p.n_views, device_cus())), dim3(kLongBlock), 0, stream, kp);
+        hipLaunchKernelGGL(k_merge_long, dim3(min(kp.T * p.n_views, 2 * device_cus())), dim3(kLongBlock), 0, stream, kp);
     }
     T4D_LAUNCH_CHECK("k_sort_long");
     {

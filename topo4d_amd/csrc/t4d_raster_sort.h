@@ -63,10 +63,12 @@ __device__ __forceinline__ uint32_t lower_bound_global(const unsigned long long 
 // the sibling run below it), log2(width)+1 dependent LDS reads; keys wait in registers between the read and the write phase.
 // log2(n/64) levels with two barriers each (a compare-exchange network needs ~60 barriers at this size).
 // PRE != 0: the keys arrive as sorted runs of PRE (k_sort_long_chunks): only the levels from there on are left.
+// dst: where the sorted keys go (default: in place)
 template <int BLOCK, int CAP, int PRE = 0>
 __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const uint32_t n, unsigned long long *s_keys,
-                                               const int tid, const int wave, const int lane)
+                                               const int tid, const int wave, const int lane, unsigned long long *dst = nullptr)
 {
+    if (dst == nullptr) dst = keys;
     constexpr int kPer = CAP / BLOCK;
     const uint32_t runs = (n + 63u) >> 6, N = runs << 6;
     for (uint32_t r = (uint32_t)wave; r < runs; r += BLOCK / 64) {
@@ -100,7 +102,7 @@ __device__ __forceinline__ void sort_chunk_lds(unsigned long long *keys, const u
             if ((uint32_t)tid + e * BLOCK < N) s_keys[np[e]] = kk[e];
         __syncthreads();
     }
-    for (uint32_t i = tid; i < n; i += BLOCK) keys[i] = s_keys[i];
+    for (uint32_t i = tid; i < n; i += BLOCK) dst[i] = s_keys[i];
     __syncthreads();
 }
 
@@ -237,20 +239,25 @@ __global__ __launch_bounds__(BLOCK) void k_sort_tiles(const KP kp)
 
 // Bins longer than kSortLdsCap keys (dense passes: 191 of 11,544 non-empty bins at P = 1M, 4096x3008, the longest 15,693 keys).
 // Work items are ordered by length class, so the long bins come first and a workgroup stops at the first bin of a shorter class.
-//   k_sort_long_chunks: every kSortLdsCap-key CHUNK of every long bin is a work unit of its own, sorted through 16 KiB of LDS by
-//     whichever workgroup it falls to (a bin of 12,614 keys: seven units in parallel);
-//   k_sort_long: a whole CU per bin - 1024 threads, 128 KiB of LDS - merges the sorted chunks of up to kLongCap keys without touching
-//     memory in between (ranking merges from runs of kSortLdsCap on: three levels for 16,384 keys); even longer bins are merged in
-//     global memory.
-// (As one kernel - runs of 64 in registers, then log2(n/64) = eight merge levels for the longest bin, by one workgroup - the long
-// bins of a 10^6-Gaussian view took 93 us behind k_sort_tiles' 45: the launch lasted as long as its longest bin.)
-constexpr int kLongScan = 1024;          // long bins a workgroup of k_sort_long_chunks counts in one go
+// Two launches, in both of which every kSortLdsCap-key CHUNK of every long bin is a work unit of its own, taken by whichever
+// workgroup it falls to (a bin of 12,614 keys: seven units in parallel):
+//   k_sort_long_chunks: sorts the chunk through 16 KiB of LDS and leaves it in the scratch arena (sort_tmp), at the bin's offsets;
+//   k_merge_long: ONE ranking pass instead of log2(chunks) merge levels - a key's final position in its bin is its position in its
+//     own chunk plus, for every other chunk, the number of keys there that are smaller (keys are unique: the Gaussian index is the
+//     low word); two keys per thread, the binary searches of four sibling chunks in lock-step (eight independent chains of
+//     dependent loads from this XCD's L2), keys scattered from the scratch arena to their final slots in the key arena.  Any bin
+//     length: no LDS, no cap.
+// (History, one 4096 x 3008 view of 10^6 Gaussians: as one kernel - runs of 64, then eight merge levels by one workgroup - the long
+// bins took 93 us behind k_sort_tiles' 45; chunks in parallel + a whole CU per bin merging up to 16,384 keys in 128 KiB of LDS: 20 +
+// 37-52 us, the launch lasting as long as its longest bin's three merge levels on ONE workgroup; the ranking pass with its searches
+// in memory: 20 + 38 us; with the siblings staged in LDS: 20 + 17-21 us - round 6.)
+constexpr int kLongScan = 1024;          // long bins a workgroup counts in one go
 
-__global__ __launch_bounds__(kLongBlock) void k_sort_long_chunks(const KP kp)
+// Calls unit(work item, first key of the chunk) for this workgroup's share of the chunks of all long bins: units u = blockIdx.x,
+// + gridDim.x, ... in the global numbering (bins in work-item order, chunks in order).  s_first [kLongScan + 1], s_wsum [kLongBlock / 64].
+template <typename F>
+__device__ __forceinline__ void for_each_long_chunk(const KP &kp, uint32_t *s_first, uint32_t *s_wsum, F &&unit)
 {
-    __shared__ unsigned long long s_keys[kSortLdsCap];
-    __shared__ uint32_t s_first[kLongScan + 1];          // s_first[i] = units in front of work item i
-    __shared__ uint32_t s_wsum[kLongBlock / 64];
     static_assert(kLongScan == kLongBlock, "one work item per thread and round");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t n_items = (uint32_t)(kp.V * kp.T);
@@ -281,10 +288,7 @@ __global__ __launch_bounds__(kLongBlock) void k_sort_long_chunks(const KP kp)
 #pragma unroll
             for (uint32_t st = kLongScan >> 1; st > 0; st >>= 1)
                 if (s_first[pos + st] <= lu) pos += st;
-            const uint4 it = kp.items[base + pos];
-            const uint32_t c = (lu - s_first[pos]) * (uint32_t)kSortLdsCap;
-            unsigned long long *keys = kp.keys + (size_t)(it.x >> 20) * kp.cap + it.y + c;
-            sort_chunk_lds<kLongBlock, kSortLdsCap>(keys, min((uint32_t)kSortLdsCap, it.z - c), s_keys, tid, wave, lane);
+            unit(kp.items[base + pos], (lu - s_first[pos]) * (uint32_t)kSortLdsCap);
         }
         units_before += total;
         if (!more) break;
@@ -292,23 +296,79 @@ __global__ __launch_bounds__(kLongBlock) void k_sort_long_chunks(const KP kp)
     }
 }
 
-__global__ __launch_bounds__(kLongBlock) void k_sort_long(const KP kp)
+__global__ __launch_bounds__(kLongBlock) void k_sort_long_chunks(const KP kp)
 {
-    __shared__ unsigned long long s_keys[kLongCap];
+    __shared__ unsigned long long s_keys[kSortLdsCap];
+    __shared__ uint32_t s_first[kLongScan + 1];          // s_first[i] = units in front of work item i
+    __shared__ uint32_t s_wsum[kLongBlock / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t n_items = (uint32_t)(kp.V * kp.T);
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint4 it = kp.items[item];
-        const int v = (int)(it.x >> 20);
-        const uint32_t off = it.y, n = it.z;
-        // The list is ordered by length CLASS (floor(log2 n)) only: a bin of exactly kSortLdsCap keys (k_sort_tiles' share) can
-        // sit in front of longer bins of the same class, so it is skipped; the first bin of a shorter class ends the loop.
-        if (n < (uint32_t)kSortLdsCap) break;
-        if (n == (uint32_t)kSortLdsCap) continue;
-        unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
-        if (n <= (uint32_t)kLongCap) sort_chunk_lds<kLongBlock, kLongCap, kSortLdsCap>(keys, n, s_keys, tid, wave, lane);
-        else sort_bin_chunked<kLongBlock, kLongCap, kSortLdsCap>(keys, kp.sort_tmp + (size_t)v * kp.cap + off, n, s_keys, tid, wave, lane);
-        __syncthreads();
-    }
+    for_each_long_chunk(kp, s_first, s_wsum, [&](const uint4 it, const uint32_t c) {
+        const size_t base = (size_t)(it.x >> 20) * kp.cap + it.y + c;
+        sort_chunk_lds<kLongBlock, kSortLdsCap>(kp.keys + base, min((uint32_t)kSortLdsCap, it.z - c), s_keys, tid, wave, lane, kp.sort_tmp + base);
+    });
 }
 
+__global__ __launch_bounds__(kLongBlock) void k_merge_long(const KP kp)
+{
+    constexpr int kGroup = 4;                            // sibling chunks staged in LDS at a time (64 KiB: two workgroups per CU)
+    __shared__ unsigned long long s_sib[kGroup * kSortLdsCap];
+    __shared__ uint32_t s_first[kLongScan + 1];
+    __shared__ uint32_t s_wsum[kLongBlock / 64];
+    constexpr int kPer = kSortLdsCap / kLongBlock;       // keys of a chunk per thread
+    static_assert(kPer == 2, "two keys per thread, their searches in lock-step");
+    const int tid = threadIdx.x;
+    for_each_long_chunk(kp, s_first, s_wsum, [&](const uint4 it, const uint32_t c) {
+        const uint32_t n = it.z;
+        const size_t base = (size_t)(it.x >> 20) * kp.cap + it.y;
+        const unsigned long long *src = kp.sort_tmp + base;
+        unsigned long long *dst = kp.keys + base;
+        const uint32_t len = min((uint32_t)kSortLdsCap, n - c);
+        unsigned long long key[kPer];
+        uint32_t rank[kPer];
+#pragma unroll
+        for (int e = 0; e < kPer; e++) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)e * kLongBlock;
+            key[e] = i < len ? src[c + i] : ~0ull;
+            rank[e] = i;                                 // position in the own chunk; every other chunk adds its keys below
+        }
+        // The sibling chunks come through LDS, kGroup at a time: a search is a chain of 12 dependent reads, and from memory each of
+        // them is a trip to the Infinity Cache (the chunks were written by other XCDs a kernel ago: ~0.7 us per step measured, 38 us
+        // for the launch); staged, a group costs one round of independent 16-byte loads and 12 LDS reads.
+        for (uint32_t s0 = 0; s0 < n; s0 += (uint32_t)(kGroup * kSortLdsCap)) {
+            const uint32_t glen = min((uint32_t)(kGroup * kSortLdsCap), n - s0);
+            __syncthreads();                             // (the previous group's - or unit's - searches have left the buffer)
+            for (uint32_t i = (uint32_t)tid * 2u; i < glen; i += 2u * kLongBlock) {
+                // (base and s0 are even multiples of 8 bytes only by luck: 8-byte loads; two per thread and round keep them in flight)
+                const unsigned long long a = src[s0 + i];
+                const unsigned long long b = i + 1u < glen ? src[s0 + i + 1u] : ~0ull;
+                s_sib[i] = a; s_sib[i + 1u] = b;
+            }
+            __syncthreads();
+            uint32_t lb[kPer][kGroup], sl[kGroup];
+#pragma unroll
+            for (int j = 0; j < kGroup; j++) {
+                const uint32_t s = s0 + (uint32_t)j * (uint32_t)kSortLdsCap;
+                sl[j] = (s < n && s != c) ? min((uint32_t)kSortLdsCap, n - s) : 0u;
+#pragma unroll
+                for (int e = 0; e < kPer; e++) lb[e][j] = 0u;
+            }
+            for (uint32_t st = (uint32_t)kSortLdsCap >> 1; st > 0; st >>= 1) {
+#pragma unroll
+                for (int j = 0; j < kGroup; j++)
+#pragma unroll
+                    for (int e = 0; e < kPer; e++) {
+                        const uint32_t p = lb[e][j] + st;
+                        if (p <= sl[j] && s_sib[j * kSortLdsCap + p - 1u] < key[e]) lb[e][j] = p;
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < kGroup; j++)
+#pragma unroll
+                for (int e = 0; e < kPer; e++)
+                    rank[e] += lb[e][j] + ((lb[e][j] < sl[j] && s_sib[j * kSortLdsCap + lb[e][j]] < key[e]) ? 1u : 0u);
+        }
+#pragma unroll
+        for (int e = 0; e < kPer; e++)
+            if ((uint32_t)tid + (uint32_t)e * kLongBlock < len) dst[rank[e]] = key[e];
+    });
+}
