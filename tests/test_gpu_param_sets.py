@@ -52,7 +52,7 @@ def _render_sets(cams_per_set, rvs, dc, dd=None, da=None, raw=False):
     return out, {k: (v.cpu().numpy() if v is not None else None) for k, v in g.items()}, batch
 
 
-@pytest.mark.parametrize("n_sets,n_cams,sh_degree", [(2, 3, None), (4, 2, None), (2, 8, 3), (3, 2, 3), (2, 2, 1)])
+@pytest.mark.parametrize("n_sets,n_cams,sh_degree", [(2, 3, None), (4, 2, None), (3, 1, None), (2, 8, 3), (3, 2, 3), (2, 2, 1)])
 def test_parameter_sets_match_the_oracle_and_one_frame_launches(n_sets, n_cams, sh_degree, render_build, monkeypatch):
     from scaffold import scene
     H = W = 96

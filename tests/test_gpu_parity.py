@@ -316,6 +316,38 @@ def test_bins_of_exactly_the_lds_sort_capacity_among_more_long_bins_than_cus():
         np.testing.assert_array_equal(st["keys"][v, off: off + want[v]], expect, err_msg=f"view {v}: bin of {want[v]} keys not sorted")
 
 
+def test_long_bins_at_the_chunk_and_group_boundaries_of_the_ranking_merge():
+    """k_sort_long_chunks + k_merge_long: bins of exactly 2, 3 and 4 chunks (4,096 / 6,144 / 8,192 keys: one LDS group of siblings),
+    one key into the next chunk or group (2,049 / 4,097 / 8,193), and an odd length in the third group (17,001).  One-tile views of
+    stacked Gaussians, the near plane cutting the list to the wanted length (as the test above)."""
+    from scaffold import reference_boundary as boundary
+    P, H, W = 17100, 16, 16
+    g = torch.Generator().manual_seed(23)
+    z = 0.5 + 1e-4 * torch.arange(P, dtype=torch.float32)
+    perm = torch.randperm(P, generator=g)
+    means = torch.stack([(torch.rand(P, generator=g) - 0.5) * 0.01, (torch.rand(P, generator=g) - 0.5) * 0.01, z], 1)[perm]
+    rv = dict(means3D=means, opacities=torch.full((P, 1), 0.02), scales=torch.full((P, 3), 1e-3),
+              rotations=torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1), colors_precomp=torch.rand(P, 3, generator=g))
+    K = np.array([[40.0, 0, W / 2], [0, 40.0, H / 2], [0, 0, 1]])
+    want = [2049, 4096, 4097, 6144, 8192, 8193, 17001, 2048, 12288]
+    cams = []
+    for n in want:
+        cut = P - n                                              # Gaussians behind the near plane (z_view <= 0.2)
+        w2c = np.eye(4, dtype=np.float32)
+        w2c[2, 3] = -(0.3 + (cut - 0.5) * 1e-4)
+        cams.append(boundary.setup_camera(W, H, K, w2c))
+    hip, _, batch = util.hip_render(cams, rv)
+    st = util.decode_state(batch)
+    assert st["status"][0] == 0
+    got = [int(x) for x in st["tile_count"][:, 0]]
+    assert got == want, got
+    for v, n in enumerate(want):
+        vis = np.nonzero(hip["radii"][v] > 0)[0]
+        expect = np.sort((st["depth"][v][vis].view(np.uint32).astype(np.uint64) << np.uint64(32)) | vis.astype(np.uint64))
+        off = int(st["tile_off"][v, 0])
+        np.testing.assert_array_equal(st["keys"][v, off: off + n], expect, err_msg=f"view {v}: bin of {n} keys not sorted")
+
+
 def test_degenerate_inputs():
     from scaffold import scene
     H = W = 48
