@@ -414,7 +414,8 @@ def drop_in_probe(dev, reps=5):
     saved = rasterizer._save_sync_mode()
     rasterizer._restore_sync_mode(("checked", False))      # what an unmodified train.py gets: the drop-in's default mode
     out = {"workload": "1 camera per iteration, P=8280, 512x375, params2rendervar -> GaussianRasterizer -> backward (train.py:661-673)",
-           "sync_mode": rasterizer.get_sync_mode(drop_in=True) + " (drop-in default: un-synchronised forward, its own backward refuses the gradients of a truncated render)"}
+           "sync_mode": rasterizer.get_sync_mode(drop_in=True) + " (drop-in default: un-synchronised forward; its own backward looks at the binning status without waiting and refuses the gradients of a truncated render)",
+           "autograd_engine_thread": bool(torch.autograd.is_multithreading_enabled())}
     try:
         for name, fn in (("it_per_s", it_full), ("it_per_s_without_params2rendervar", it_raster)):
             for i in range(60):
@@ -434,7 +435,9 @@ def drop_in_probe(dev, reps=5):
         rasterizer._restore_sync_mode(saved)
     out["note"] = ("host-bound: an iteration is the reference's own torch ops (params2rendervar forward + autograd backward: ~4 k it/s on "
                    "their own) plus the drop-in call (it_per_s_without_params2rendervar); median of the runs; GPU time per view is "
-                   "single_view.gpu_us_per_view, the loop without autograd is full_iteration")
+                   "single_view.gpu_us_per_view, the loop without autograd is full_iteration; importing the drop-in module runs the backward on "
+                   "the calling thread (autograd_engine_thread false): with torch's worker thread the same loop ran at 4-5 k OR 8-9 k it/s "
+                   "(profiles/r06_dropin_regimes.txt)")
     return out
 
 
