@@ -147,8 +147,16 @@ inline int seg_mode(const T4DProblem &p)
 inline bool seg_capable(const T4DProblem &p) { return seg_mode(p) != 0; }
 // Segment slots of a view.  Tile t (arena offset off, n pairs) owns the slots floor(off / kSeg) + t ... + ceil(n / kSeg) - 1:
 // disjoint from tile to tile ((off + n) / kSeg - off / kSeg >= floor(n / kSeg)) without a prefix sum over the tiles.
+// seg_mode 2 (only the tiles of at least kSegLongMin pairs own slots): floor(off / kSeg) + floor(off / kSegLongMin) instead - the
+// second term grows by at least one from a long tile to the next ((off + n) / kSegLongMin - off / kSegLongMin >= 1 for n >=
+// kSegLongMin), which is all the "+ t" was for: cap / kSeg + cap / kSegLongMin slots instead of cap / kSeg + T (one
+// 4096 x 3008 view carried 48,128 x 6 KB = 290 MB of snapshot slots for tiles that can never own one).
 inline int seg_positions(const T4DProblem &p) { return (p.n_views == 1 && seg_mode(p) == 1) ? kSegOne : kSeg; }
-inline size_t seg_slots_per_view(const T4DProblem &p, size_t T) { return (size_t)p.pair_capacity / (size_t)seg_positions(p) + T + 1; }
+inline size_t seg_slots_per_view(const T4DProblem &p, size_t T)
+{
+    if (seg_mode(p) == 2) return (size_t)p.pair_capacity / (size_t)kSeg + (size_t)p.pair_capacity / (size_t)kSegLongMin + 2;
+    return (size_t)p.pair_capacity / (size_t)seg_positions(p) + T + 1;
+}
 
 Layout make_layout(const T4DProblem &p)
 {
@@ -232,6 +240,7 @@ struct KP {
     unsigned long long *host_status;  // T4D_FLAG_ASYNC_STATUS on a one-view launch: the caller's pinned 16 bytes, written by the kernel itself
     // (behind everything else: the kernels of every other launch shape read their arguments from the offsets they always had)
     uint32_t seg_min_pairs;          // tiles of fewer pairs are not segmented (0: every tile is - small launches; kSegLongMin: seg_mode 2)
+    uint32_t slots_by_offset;        // seg_mode 2: a long tile's first slot is off / kSeg + off / kSegLongMin (seg_slot0), not off / kSeg + tile
     uint32_t views_per_set;          // T4DProblem.views_per_param_set: view v reads the per-Gaussian inputs of parameter set v / views_per_set (0: one set for all views)
 };
 
@@ -278,6 +287,13 @@ __device__ __forceinline__ ViewRecord load_view_record(const float *views, const
 __device__ __forceinline__ size_t param_row0(const KP &kp, const int v)
 {
     return kp.views_per_set ? (size_t)((uint32_t)v / kp.views_per_set) * (size_t)kp.P : (size_t)0;
+}
+
+// first segment slot (within its view) of the tile at arena offset `off`: see seg_slots_per_view
+__device__ __forceinline__ uint32_t seg_slot0(const KP &kp, const uint32_t off, const uint32_t tile)
+{
+    static_assert((kSegLongMin & (kSegLongMin - 1)) == 0, "a shift");
+    return (off >> kp.seg_shift) + (kp.slots_by_offset ? off / (uint32_t)kSegLongMin : tile);
 }
 
 // wave64 inclusive prefix sum (uint32)
@@ -606,6 +622,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.snap = reinterpret_cast<float *>(st + L.snap);
     kp.slots_per_view = seg_capable(p) ? (uint32_t)seg_slots_per_view(p, (size_t)kp.T) : 0u;
     kp.seg_shift = seg_positions(p) == 64 ? 6u : 7u;
+    kp.slots_by_offset = seg_mode(p) == 2 ? 1u : 0u;
     // seg_mode 2: the caller's word that no list is long (T4D_FLAG_NO_LONG_BINS) keeps every tile whole
     kp.seg_min_pairs = seg_mode(p) == 2 ? ((p.flags & T4D_FLAG_NO_LONG_BINS) ? 0xffffffffu : (uint32_t)kSegLongMin) : 0u;
     static_assert(kSegOne == 64 && kSeg == 128, "seg_shift assumes segment lengths of 64 and 128");

@@ -352,7 +352,7 @@ __device__ __forceinline__ void write_segment_slots(const KP &kp, const uint32_t
     if (kp.slots_per_view == 0u || n == 0u) return;
     if (BIG && n < kp.seg_min_pairs) return;
     const uint32_t nseg = (n + (1u << kp.seg_shift) - 1u) >> kp.seg_shift;
-    uint4 *tab = kp.slot_tab + (size_t)(id >> 20) * kp.slots_per_view + (off >> kp.seg_shift) + (id & 0xfffffu);
+    uint4 *tab = kp.slot_tab + (size_t)(id >> 20) * kp.slots_per_view + seg_slot0(kp, off, id & 0xfffffu);
     for (uint32_t j = 0; j < nseg; j++) tab[j] = make_uint4(id, off, n, j | 0x80000000u);
 }
 

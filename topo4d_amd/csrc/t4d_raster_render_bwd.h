@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     // a big one-view launch: the tiles the forward cut into segments (it wrote their slot-table entries with their snapshots) are
     // the segmented launch's
     if (!SEG && LONG && n >= kp.seg_min_pairs &&
-        kp.slot_tab[(size_t)v * kp.slots_per_view + (off >> kp.seg_shift) + (uint32_t)t_].w != 0u) continue;
+        kp.slot_tab[(size_t)v * kp.slots_per_view + seg_slot0(kp, off, (uint32_t)t_)].w != 0u) continue;
     const unsigned long long *keys = kp.keys + (size_t)v * kp.cap + off;
     const float *r2_in = kp.cut_r2 + (size_t)v * kp.cap + off;
     const float2 *xy = kp.xy + (size_t)v * kp.P;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
         // finished wave, so nothing is read for such a pixel).
         const uint32_t p = (uint32_t)(seg_j + 1) * kSeg;
         if (last_contributor > p) {
-            const float *sb = kp.snap + ((size_t)v * kp.slots_per_view + off / kSeg + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
+            const float *sb = kp.snap + ((size_t)v * kp.slots_per_view + seg_slot0(kp, off, (uint32_t)t_)) * (kSnapFloats * kBlock) + tid;
             const float *sp = sb + (size_t)seg_j * (kSnapFloats * kBlock), *sf = sb + (size_t)(nb - 1) * (kSnapFloats * kBlock);
             const float Tp = sp[0];
             float suf = fmaf(sf[kBlock] - sp[kBlock], dp0, fmaf(sf[2 * kBlock] - sp[2 * kBlock], dp1, (sf[3 * kBlock] - sp[3 * kBlock]) * dp2));

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     // segmented backward: this tile's snapshot slots (a tile of one segment keeps none: its replay starts at the list's end)
     float *snap = nullptr;
     if (SEG && n > (uint32_t)kSeg && n >= kp.seg_min_pairs)
-        snap = kp.snap + ((size_t)v * kp.slots_per_view + off / kSeg + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
+        snap = kp.snap + ((size_t)v * kp.slots_per_view + seg_slot0(kp, off, (uint32_t)t_)) * (kSnapFloats * kBlock) + tid;
 
     int px, py;
     tile_pixel(tid, tx, ty, px, py);

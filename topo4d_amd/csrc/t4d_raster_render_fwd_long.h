@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         const bool inside = px < kp.W && py < kp.H;
         const v2f pix_f = { (float)px, (float)py };
         const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
-        float *slot0 = kp.snap + ((size_t)v * kp.slots_per_view + off / kS + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
+        float *slot0 = kp.snap + ((size_t)v * kp.slots_per_view + seg_slot0(kp, off, (uint32_t)t_)) * (kSnapFloats * kBlock) + tid;
         float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
         uint32_t last_contributor = 0u;
         bool mine = inside;                          // does this pixel take splats in this launch?
@@ -198,14 +198,14 @@ __global__ __launch_bounds__(kBlock) void k_fwd_long_prefix(const KP kp)
         const uint32_t off = it.y, n = it.z;
         if (n < kp.seg_min_pairs) break;             // ordered by length class: ...
         const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
-        if (kp.slot_tab[(size_t)v * kp.slots_per_view + off / kS + (uint32_t)t_].w == 0u) continue;      // (... a class may hold shorter tiles too)
+        if (kp.slot_tab[(size_t)v * kp.slots_per_view + seg_slot0(kp, off, (uint32_t)t_)].w == 0u) continue;      // (... a class may hold shorter tiles too)
         const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
         int px, py;
         tile_pixel(tid, tx, ty, px, py);
         const bool inside = px < kp.W && py < kp.H;
         const size_t HW = (size_t)kp.H * kp.W, pix = (size_t)py * kp.W + px;
         const uint32_t nb = (n + (uint32_t)kS - 1u) / (uint32_t)kS;
-        float *slot0 = kp.snap + ((size_t)v * kp.slots_per_view + off / kS + (uint32_t)t_) * (kSnapFloats * kBlock) + tid;
+        float *slot0 = kp.snap + ((size_t)v * kp.slots_per_view + seg_slot0(kp, off, (uint32_t)t_)) * (kSnapFloats * kBlock) + tid;
         float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
         uint32_t last = 0u, stop_seg = 0xffffffffu;
         // Four segments' records per round, and the NEXT round's requested before this round's are used and overwritten (loads and
