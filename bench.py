@@ -254,7 +254,8 @@ class Workload:
             if self.allreduce_grads:
                 # data-parallel training step over a view shard: the view-summed parameter gradients are summed over the ranks
                 # (~14 floats x P; changes train.py:661-673's one-Adam-step-per-view schedule, so it is optional)
-                summed = [t.sum(0) for t in g.values() if t is not None]
+                # (several frames per launch set: views are frame-major - the sum runs over a frame's views, one gradient per frame)
+                summed = [t.reshape(self.G, self.V, *t.shape[1:]).sum(1) for t in g.values() if t is not None]
                 self.t4d_dist.all_reduce_grads(summed)
             if self.gather:
                 out, work = self.t4d_dist.gather_losses_async(losses, self.gath_bufs[k])
