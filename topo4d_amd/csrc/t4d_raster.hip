@@ -121,7 +121,7 @@ std::vector<ProfRec> g_prof;
 // ---------------------------------------------------------------------------------------------------------
 struct Layout {
     size_t status, view_total, view_cursor, tile_count, bucket_fill, slot_tab, zero_end;
-    size_t snap;
+    size_t snap, live;
     size_t tile_off, chunk_sum, order, items, xy, depth, conic_opacity, rgb, clamped, pair_off, pair_rank, keys, sort_tmp, final_T, n_contrib, total;
 };
 
@@ -131,6 +131,7 @@ struct DevStatus {            // first bytes of the state buffer
     unsigned long long total_pairs;       // ... the 16 bytes T4D_FLAG_ASYNC_STATUS copies out end here
     uint32_t max_tile_pairs;              // longest tile list of the call (reported as T4DStatus.max_tile_pairs)
     uint32_t grid_sync;                   // arrival counter of k_front_small's one grid-wide barrier
+    uint32_t live_segments;               // seg_mode 2: entries of the live-segment list (the long tiles' segments, Layout::live)
 };
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -175,6 +176,8 @@ Layout make_layout(const T4DProblem &p)
     L.slot_tab = o;      o = align_up(o + slots * 16);           // (zeroed with the counters: an all-zero entry is "no segment")
     L.zero_end = o;
     L.snap = o;          o = align_up(o + slots * kSnapFloats * kBlock * 4);
+    // seg_mode 2: the slots that hold a segment, compact (the table itself is mostly empty: a few thousand segments in 60,000 slots)
+    L.live = o;          o = align_up(o + (seg_mode(p) == 2 ? slots * 4 : 0));
     L.tile_off = o;      o = align_up(o + V * T * 4);
     L.chunk_sum = o;     o = align_up(o + V * ((T + kScanChunk - 1) / kScanChunk) * 4);
     L.order = o;         o = align_up(o + (size_t)kBuckets * V * T * 4);
@@ -240,6 +243,7 @@ struct KP {
     unsigned long long *host_status;  // T4D_FLAG_ASYNC_STATUS on a one-view launch: the caller's pinned 16 bytes, written by the kernel itself
     // (behind everything else: the kernels of every other launch shape read their arguments from the offsets they always had)
     uint32_t seg_min_pairs;          // tiles of fewer pairs are not segmented (0: every tile is - small launches; kSegLongMin: seg_mode 2)
+    uint32_t *live;                  // seg_mode 2: slot-table indices of the live segments, status->live_segments of them (order: as the item builders got to them)
     uint32_t slots_by_offset;        // seg_mode 2: a long tile's first slot is off / kSeg + off / kSegLongMin (seg_slot0), not off / kSeg + tile
     uint32_t views_per_set;          // T4DProblem.views_per_param_set: view v reads the per-Gaussian inputs of parameter set v / views_per_set (0: one set for all views)
 };
@@ -620,6 +624,7 @@ void fill_common(KP &kp, const T4DProblem &p, const Layout &L, char *st)
     kp.n_contrib = reinterpret_cast<uint32_t *>(st + L.n_contrib);
     kp.slot_tab = reinterpret_cast<uint4 *>(st + L.slot_tab);
     kp.snap = reinterpret_cast<float *>(st + L.snap);
+    kp.live = reinterpret_cast<uint32_t *>(st + L.live);
     kp.slots_per_view = seg_capable(p) ? (uint32_t)seg_slots_per_view(p, (size_t)kp.T) : 0u;
     kp.seg_shift = seg_positions(p) == 64 ? 6u : 7u;
     kp.slots_by_offset = seg_mode(p) == 2 ? 1u : 0u;

@@ -352,8 +352,15 @@ __device__ __forceinline__ void write_segment_slots(const KP &kp, const uint32_t
     if (kp.slots_per_view == 0u || n == 0u) return;
     if (BIG && n < kp.seg_min_pairs) return;
     const uint32_t nseg = (n + (1u << kp.seg_shift) - 1u) >> kp.seg_shift;
-    uint4 *tab = kp.slot_tab + (size_t)(id >> 20) * kp.slots_per_view + seg_slot0(kp, off, id & 0xfffffu);
+    const size_t first = (size_t)(id >> 20) * kp.slots_per_view + seg_slot0(kp, off, id & 0xfffffu);
+    uint4 *tab = kp.slot_tab + first;
     for (uint32_t j = 0; j < nseg; j++) tab[j] = make_uint4(id, off, n, j | 0x80000000u);
+    if (BIG && kp.slots_by_offset) {
+        // the long tiles' segments, compact: the kernels that work on them take entry k, k + grid, ... of this list - even shares
+        // and no walk over the (mostly empty) table.  One returning atomic per long tile (a few hundred per view).
+        const uint32_t at = atomicAdd(&kp.status->live_segments, nseg);
+        for (uint32_t j = 0; j < nseg; j++) kp.live[at + j] = (uint32_t)first + j;      // (one view: the index fits)
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter(const KP kp)

@@ -206,20 +206,10 @@ __global__ __launch_bounds__(kBlock) T4D_BWD_ATTR void k_render_bwd(const KP kp)
     for (int i = tid; i < kSlabs * (kBwdBatch + 1) * kAcc; i += kBlock) (&s_acc[0][0][0])[i] = 0.f;   // slabs are all-zero between batches
     // work items: the length-ordered tile list (whole tiles), ONE slot of the slot table (segments of a small launch), or a strided
     // walk over the mostly empty table of a big one-view launch (LONG)
-    unsigned long long slot_live = 0ull;             // LONG: which of this workgroup's next 64 slots hold a segment
-    uint32_t round = 0u;
-    for (uint32_t item = blockIdx.x; item < (SEG ? (LONG ? (uint32_t)kp.V * kp.slots_per_view : blockIdx.x + 1u) : (uint32_t)(kp.V * kp.T)); item += kp.tile_blocks) {
-    if (SEG && LONG) {
-        // one gather per 64 slots instead of one dependent scalar load per slot (2,048 workgroups over 79,000 slots: 39 round
-        // trips each, 20-40 us of a launch that has a few thousand segments to do); every wave sees the same mask
-        const uint32_t r_ = round++;
-        if ((r_ & 63u) == 0u) {
-            const uint32_t s_ = item + (uint32_t)lane * kp.tile_blocks;
-            slot_live = __ballot(s_ < (uint32_t)kp.V * kp.slots_per_view && kp.slot_tab[s_].w != 0u);
-        }
-        if (((slot_live >> (r_ & 63u)) & 1ull) == 0ull) continue;      // workgroup-uniform
-        it = kp.slot_tab[item];
-    }
+    // (LONG segments: entries k, k + grid, ... of the compact list of live segments - the table itself is mostly empty, and a
+    // strided walk over it, even with one gather per 64 slots, cost 20-40 us and dealt the segments out unevenly)
+    for (uint32_t item = blockIdx.x; item < (SEG ? (LONG ? kp.status->live_segments : blockIdx.x + 1u) : (uint32_t)(kp.V * kp.T)); item += kp.tile_blocks) {
+    if (SEG && LONG) it = kp.slot_tab[kp.live[item]];
     if (!SEG) it = kp.items[item];
     const int seg_j = SEG ? (int)(it.w & 0x7fffffffu) : 0;           // this item's segment: list positions [seg_j kSeg, (seg_j + 1) kSeg)
     const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);

@@ -37,17 +37,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
     if (tid < kRec / 4) reinterpret_cast<float *>(s_rec + kNull * kRec)[tid] = 0.f;
-    const uint32_t n_slots = (uint32_t)kp.V * kp.slots_per_view;
-    unsigned long long slot_live = 0ull;
-    uint32_t round = 0u;
-    for (uint32_t item = blockIdx.x; item < n_slots; item += kp.tile_blocks) {
-        const uint32_t r_ = round++;                 // (one gather per 64 slots of the mostly empty table: see k_render_bwd<.., LONG>)
-        if ((r_ & 63u) == 0u) {
-            const uint32_t s_ = item + (uint32_t)lane * kp.tile_blocks;
-            slot_live = __ballot(s_ < n_slots && kp.slot_tab[s_].w != 0u);
-        }
-        if (((slot_live >> (r_ & 63u)) & 1ull) == 0ull) continue;          // workgroup-uniform
-        const uint4 it = kp.slot_tab[item];
+    const uint32_t n_live = kp.status->live_segments;        // (the compact list of the segments: write_segment_slots)
+    for (uint32_t k = blockIdx.x; k < n_live; k += kp.tile_blocks) {
+        const uint4 it = kp.slot_tab[kp.live[k]];
         const uint32_t j = it.w & 0x7fffffffu;
         const int v = (int)(it.x >> 20), t_ = (int)(it.x & 0xfffffu);
         const int ty = t_ / kp.gx, tx = t_ - ty * kp.gx;
