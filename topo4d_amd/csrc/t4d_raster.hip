@@ -784,6 +784,10 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     // one-pass ranking sort (T4D_FLAG_SHORT_BINS): then the render workgroup of a tile sorts its own bin (no launch at all).
     const bool lat = latency_launch_fwd(kp.T * p.n_views, p.flags);
     kp.fused_sort = (lat && (p.flags & T4D_FLAG_SHORT_BINS) != 0 && getenv("T4D_NO_FUSED_SORT") == nullptr) ? 1u : 0u;
+    // a big one-view launch that may hold long lists: its long tiles go through the depth-parallel kernels, and the throughput forward
+    // that renders the others sorts its own tiles' bins first (k_render_fwd, FUSE): no k_sort_tiles launch
+    const bool long_fwd = kp.slots_per_view != 0u && kp.seg_min_pairs != 0xffffffffu && seg_mode(p) == 2 && !lat && getenv("T4D_NO_LONG_FWD") == nullptr;
+    if (long_fwd && getenv("T4D_NO_FUSED_SORT") == nullptr) kp.fused_sort = 1u;
     if (!kp.fused_sort) {
         ProfScope ps_(stream, K_SORT_TILES);
         // (1024 threads per bin only pay when some bin is long: with the caller's word that every bin fits the ranking sort, a
@@ -812,7 +816,6 @@ T4D_EXPORT int t4d_rasterize_forward(const T4DProblem *prob, const T4DForwardIO 
     const bool seg_one = seg && seg_positions(p) == kSegOne;
     // a big one-view launch that may hold long lists: those tiles go through the depth-parallel kernels (three launches over the
     // slot table, t4d_raster_render_fwd_long.h); the others through the throughput build, which leaves the long ones out
-    const bool long_fwd = seg && seg_mode(p) == 2 && !lat && getenv("T4D_NO_LONG_FWD") == nullptr;
     if (long_fwd) {
         { ProfScope ps_(stream, K_RENDER_FWD);
         hipLaunchKernelGGL((k_render_fwd<false, kFwdBatch, 0, true, true>), fgrid, dim3(kBlock), 0, stream, kp);

@@ -213,12 +213,33 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     constexpr int kListStride = kSub + 8;      // u16 entries per row list (multiple of 4: 8-byte aligned rows)
     constexpr int kRec = 48;                         // bytes per staged splat: xy, cut-off r2 (12, +4 pad) | scaled conic + opacity | rgb + depth
     static_assert(kFB <= kBlock && kFB % 64 == 0 && kFB % kSub == 0, "one staging thread per slot (it clears the slot when the list is shorter)");
-    __shared__ __attribute__((aligned(16))) unsigned char s_rec[(kFB + 1) * kRec];
-    __shared__ __attribute__((aligned(8))) unsigned short s_list[4][4][kListStride];
-    __shared__ uint32_t s_wave_done[4];
     // latency build: the workgroup sorts its own tile's bin first (one launch and one trip through memory less than
-    // k_sort_tiles -> k_render_fwd) and stages from the sorted keys it still holds
-    __shared__ unsigned long long s_sort[LAT ? kSortLdsCap : 1];
+    // k_sort_tiles -> k_render_fwd) and stages from the sorted keys it still holds: a sort buffer of its own.
+    // FUSE (the one-view dense pass, LONG): the workgroup sorts the bins of ALL its tiles before it renders any of them, through
+    // the staging area itself (records and lists are not in use yet: the CU keeps its seven workgroups).  Such a launch is one frame
+    // at a time by nature (Topo4D's texture loop), so k_sort_tiles - 44 us with nothing else on the chip - cannot hide in another
+    // frame's gaps; here a workgroup's sorting runs beside the other workgroups' blending.  For launches with frames in flight the
+    // same fusion measured 1.7 % SLOWER (tools/experiments/README.md, round 6): they keep k_sort_tiles, and their instantiations of
+    // this kernel are untouched by the `if constexpr` below.
+    constexpr bool FUSE = LONG;
+    constexpr int kRecBytes = ((kFB + 1) * kRec + 15) / 16 * 16;
+    unsigned char *s_rec;
+    unsigned short (*s_list)[4][kListStride];
+    unsigned long long *s_sort;
+    if constexpr (FUSE) {
+        constexpr int kStage = kRecBytes + 4 * 4 * kListStride * 2;
+        constexpr int kRaw = kStage < kSortLdsCap * 8 ? kSortLdsCap * 8 : kStage;
+        __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRaw];
+        s_rec = s_raw;
+        s_list = reinterpret_cast<unsigned short (*)[4][kListStride]>(s_raw + kRecBytes);
+        s_sort = reinterpret_cast<unsigned long long *>(s_raw);
+    } else {
+        __shared__ __attribute__((aligned(16))) unsigned char s_rec_[(kFB + 1) * kRec];
+        __shared__ __attribute__((aligned(8))) unsigned short s_list_[4][4][kListStride];
+        __shared__ unsigned long long s_sort_[LAT ? kSortLdsCap : 1];
+        s_rec = s_rec_; s_list = s_list_; s_sort = s_sort_;
+    }
+    __shared__ uint32_t s_wave_done[4];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, row = lane >> 4;
     // fill workgroups are spread evenly over the launch: workgroup b is one iff floor(b F / total) steps up at b
@@ -227,6 +248,23 @@ __global__ __launch_bounds__(kBlock) T4D_FWD_ATTR void k_render_fwd(const KP kp)
     if ((uint32_t)(((unsigned long long)(blockIdx.x + 1u) * kp.fill_blocks) / total_blocks) != fills_before) {
         fill_empty_tile_row(kp, fills_before);
         return;
+    }
+    if constexpr (FUSE) {
+        if (kp.fused_sort) {
+            // (in a loop of its own: inside the tile loop the sort's registers lived beside the walk's - 17 vector and 103 scalar
+            // spills under the 72-register budget.  Also the bin of a tile the depth-parallel kernels render - exactly kSortLdsCap
+            // pairs: the long-bin kernels take only longer ones)
+            for (uint32_t item = blockIdx.x - fills_before; item < (uint32_t)(kp.V * kp.T); item += kp.tile_blocks) {
+                const uint4 it = kp.items[item];
+                if (it.w == 0u) break;
+                if (it.z > 1u) {
+                    sort_one_bin<false, kBlock>(kp, (int)(it.x >> 20), it.y, it.z, s_sort, tid, wave, lane);
+                    __syncthreads();                 // the sort buffer is reused by the next bin
+                }
+            }
+            __threadfence_block();                   // the sorted keys are staged from memory below, by other threads of this workgroup
+            __syncthreads();
+        }
     }
     if (tid < kRec / 4) reinterpret_cast<float *>(s_rec + kNull * kRec)[tid] = 0.f;
     for (uint32_t item = blockIdx.x - fills_before; item < (uint32_t)(kp.V * kp.T); item += kp.tile_blocks) {
