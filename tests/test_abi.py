@@ -42,7 +42,7 @@ def test_struct_layouts_match_ctypes():
 #include "topo4d_raster.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(T4DProblem), sizeof(T4DStatus), sizeof(T4DForwardIO), sizeof(T4DBackwardIO), sizeof(T4DKernelTime));
-  printf("%zu %zu %zu\n", offsetof(T4DProblem, pair_capacity), offsetof(T4DProblem, flags), offsetof(T4DProblem, scale_modifier));
+  printf("%zu %zu %zu %zu\n", offsetof(T4DProblem, pair_capacity), offsetof(T4DProblem, flags), offsetof(T4DProblem, scale_modifier), offsetof(T4DProblem, views_per_param_set));
   printf("%zu %zu\n", offsetof(T4DForwardIO, state_bytes), offsetof(T4DBackwardIO, scratch_bytes));
   printf("%d %d %d\n", T4D_ABI_VERSION, T4D_VIEW_FLOATS, T4D_GRAD_PAIR_FLOATS);
   return 0; }'''
@@ -56,7 +56,8 @@ int main(void) {
     assert sizes == [C.sizeof(_lib.T4DProblem), C.sizeof(_lib.T4DStatus), C.sizeof(_lib.T4DForwardIO),
                      C.sizeof(_lib.T4DBackwardIO), C.sizeof(_lib.T4DKernelTime)]
     offs = [int(x) for x in lines[1].split()]
-    assert offs == [_lib.T4DProblem.pair_capacity.offset, _lib.T4DProblem.flags.offset, _lib.T4DProblem.scale_modifier.offset]
+    assert offs == [_lib.T4DProblem.pair_capacity.offset, _lib.T4DProblem.flags.offset, _lib.T4DProblem.scale_modifier.offset,
+                    _lib.T4DProblem.views_per_param_set.offset]
     offs2 = [int(x) for x in lines[2].split()]
     assert offs2 == [_lib.T4DForwardIO.state_bytes.offset, _lib.T4DBackwardIO.scratch_bytes.offset]
     consts = [int(x) for x in lines[3].split()]
